@@ -1,0 +1,567 @@
+/* ORACLE (test infrastructure): index construction restated from src/lib.rs:675-893
+ * (generate_layer, generate), 1070-1154 (link), 1463-1544 (recall, improve_neighbors),
+ * 1546-1686 (improve_index, promotion excluded), 1830-1852 (choose_n_1), 1883-1960
+ * (partition arithmetic) and src/search.rs:13-82 (initial partitions).
+ *
+ * The reference build is not reproducible (thread_rng shuffle lib.rs:832, rand's StdRng
+ * streams lib.rs:729,1847, lock-order races lib.rs:797-815,1107-1153), so this is the
+ * DETERMINISTIC variant the HIP build is bit-compared with:
+ *   - every PRNG draw comes from the counter-based generators in orc_util.c;
+ *   - every "insert into another node's row under a lock" step is evaluated against a
+ *     snapshot and resolved as  row' = best-W by (distance, id) of  row U proposals,
+ *     which is what the sequential reference code produces for (d,id)-sorted rows.
+ * "parity unpinned" vs the Rust crate at graph level; pinned properties are recall,
+ * layer invariants and the toy-index golden tests. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orc_internal.h"
+
+void orc_default_build_params(orc_build_params *bp) {
+  /* src/parameters.rs:10-64 */
+  bp->order = 12;
+  bp->zero_layer_neighborhood_size = 48;
+  bp->neighborhood_size = 24;
+  bp->optimization.promotion_threshold = 0.01f;
+  bp->optimization.neighborhood_threshold = 0.01f;
+  bp->optimization.recall_proportion = 0.1f;
+  bp->optimization.promotion_proportion = 1.0f;
+  bp->optimization.search.number_of_candidates = 300;
+  bp->optimization.search.upper_layer_candidate_count = 300;
+  bp->optimization.search.probe_depth = 2;
+  bp->initial_partition_search.number_of_candidates = 6;
+  bp->initial_partition_search.upper_layer_candidate_count = 6;
+  bp->initial_partition_search.probe_depth = 2;
+  bp->seed = 0;
+  bp->max_link_rounds = 0;
+}
+
+/* ---------------------------------------------------------------- partitions */
+
+/* calculate_partitions_from_bottom  src/lib.rs:1883-1893 (f32 arithmetic as written) */
+static uint32_t partitions_from_bottom(uint64_t total, uint64_t order, uint64_t *out, uint32_t max_out) {
+  float lc = ceilf(logf((float)total) / logf((float)order));
+  uint64_t layer_count = (lc != lc || lc < 0.0f) ? 0 : (uint64_t)lc; /* `as usize` saturates */
+  if (layer_count < 1) layer_count = 1;
+  uint64_t size = total;
+  uint32_t n = 0;
+  for (uint64_t i = 0; i < layer_count && n < max_out; i++) {
+    out[n++] = size;
+    size /= order;
+  }
+  return n;
+}
+
+/* calculate_partitions  src/lib.rs:1895-1899 */
+uint32_t orc_calculate_partitions(uint64_t total, uint64_t order, uint64_t *out, uint32_t max_out) {
+  uint32_t n = partitions_from_bottom(total, order, out, max_out);
+  for (uint32_t i = 0; i < n / 2; i++) {
+    uint64_t t = out[i];
+    out[i] = out[n - 1 - i];
+    out[n - 1 - i] = t;
+  }
+  return n;
+}
+
+/* calculate_partitions_for_additions  src/lib.rs:1901-1960 */
+uint32_t orc_calculate_partitions_for_additions(const uint64_t *sizes, uint32_t n_sizes,
+                                                uint64_t new_vecs, uint64_t order, uint64_t *out,
+                                                uint32_t max_out) {
+  uint64_t tmp[128];
+  uint32_t n = partitions_from_bottom(sizes[0] + new_vecs, order, tmp, 128);
+  while (n < n_sizes) tmp[n++] = 0;
+  for (uint32_t i = 0; i < n; i++)
+    if (i < n_sizes && sizes[i] > tmp[i]) tmp[i] = sizes[i];
+  uint64_t last = 0;
+  for (uint32_t i = n; i-- > 0;) {
+    if (last > tmp[i]) tmp[i] = last;
+    last = tmp[i];
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (i < n_sizes) tmp[i] -= sizes[i];
+  last = 0;
+  for (uint32_t i = n; i-- > 0;) {
+    if (last > tmp[i]) tmp[i] = last;
+    last = tmp[i];
+  }
+  uint32_t m = n < max_out ? n : max_out;
+  memcpy(out, tmp, sizeof(uint64_t) * m);
+  return m;
+}
+
+/* ---------------------------------------------------------------- helpers */
+
+typedef struct {
+  float d;
+  uint64_t id;
+} nd_pair;
+
+static int nd_cmp(const void *a, const void *b) {
+  const nd_pair *x = (const nd_pair *)a, *y = (const nd_pair *)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  if (x->id < y->id) return -1;
+  if (x->id > y->id) return 1;
+  return 0;
+}
+
+static int u64_cmp(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* sort (d,id), dedup(), drop `self`, take W, pad  (src/lib.rs:757-764) */
+static void finish_row(nd_pair *list, uint64_t m, uint64_t self, uint64_t W, uint64_t *row_ids,
+                       float *row_d) {
+  qsort(list, m, sizeof(nd_pair), nd_cmp);
+  uint64_t out = 0;
+  for (uint64_t k = 0; k < m && out < W; k++) {
+    if (k > 0 && list[k].id == list[k - 1].id && list[k].d == list[k - 1].d) continue; /* dedup */
+    if (list[k].id == self) continue;
+    row_ids[out] = list[k].id;
+    row_d[out] = list[k].d;
+    out++;
+  }
+  for (; out < W; out++) {
+    row_ids[out] = ORC_EMPTY;
+    row_d[out] = ORC_FMAX;
+  }
+}
+
+/* row'[t] = best-W by (d,id) of row[t] U incoming[t]; incoming built from `prop_*`
+ * (target, source, d) triples.  Deterministic form of the RwLock'd insert passes
+ * (src/lib.rs:797-815 and 1118-1147). Returns the number of entries that are new. */
+static uint64_t merge_proposals(uint64_t n, uint64_t W, uint64_t *rows, float *rows_d,
+                                const uint64_t *prop_t, const uint64_t *prop_s, const float *prop_d,
+                                uint64_t np, int threads) {
+  uint64_t *start = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
+  for (uint64_t k = 0; k < np; k++) start[prop_t[k] + 1]++;
+  for (uint64_t t = 0; t < n; t++) start[t + 1] += start[t];
+  uint64_t *fill = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1));
+  memcpy(fill, start, sizeof(uint64_t) * (n + 1));
+  nd_pair *inc = (nd_pair *)malloc(sizeof(nd_pair) * (np ? np : 1));
+  for (uint64_t k = 0; k < np; k++) {
+    nd_pair p = {prop_d[k], prop_s[k]};
+    inc[fill[prop_t[k]]++] = p;
+  }
+  free(fill);
+  uint64_t added = 0;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 64) reduction(+ : added)
+  for (uint64_t t = 0; t < n; t++) {
+    uint64_t cnt = start[t + 1] - start[t];
+    if (cnt == 0) continue;
+    nd_pair *list = (nd_pair *)malloc(sizeof(nd_pair) * (W + cnt));
+    uint64_t m = 0;
+    uint64_t *old = (uint64_t *)malloc(sizeof(uint64_t) * W);
+    uint64_t nold = 0;
+    for (uint64_t k = 0; k < W; k++) {
+      if (rows[t * W + k] == ORC_EMPTY) continue;
+      nd_pair p = {rows_d[t * W + k], rows[t * W + k]};
+      list[m++] = p;
+      old[nold++] = p.id;
+    }
+    for (uint64_t k = 0; k < cnt; k++) list[m++] = inc[start[t] + k];
+    finish_row(list, m, t, W, rows + t * W, rows_d + t * W);
+    for (uint64_t k = 0; k < W; k++) {
+      uint64_t id = rows[t * W + k];
+      if (id == ORC_EMPTY) break;
+      int found = 0;
+      for (uint64_t j = 0; j < nold; j++)
+        if (old[j] == id) {
+          found = 1;
+          break;
+        }
+      if (!found) added++;
+    }
+    free(old);
+    free(list);
+  }
+  free(inc);
+  free(start);
+  return added;
+}
+
+typedef struct {
+  uint64_t key; /* ORC_EMPTY = None */
+  float d;
+  uint64_t node;
+} gm_t;
+
+static int gm_cmp(const void *a, const void *b) {
+  const gm_t *x = (const gm_t *)a, *y = (const gm_t *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  if (x->d != y->d) return x->d < y->d ? -1 : 1;
+  return x->node < y->node ? -1 : (x->node > y->node ? 1 : 0);
+}
+
+/* ---------------------------------------------------------------- generate_layer */
+
+/* Hnsw::generate_layer  src/lib.rs:675-823 (new_top = false) */
+int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_t W,
+                       const orc_build_params *bp, int threads) {
+  if (n == 0 || W == 0) return -3; /* assert!(!vs.is_empty()) :683 */
+  const orc_store *S = &ix->store;
+  int T = threads > 0 ? threads : 1;
+  uint64_t *vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  memcpy(vs, vs_in, sizeof(uint64_t) * n);
+  qsort(vs, n, sizeof(uint64_t), u64_cmp); /* vs.sort() :685 */
+  uint64_t *rows = (uint64_t *)malloc(sizeof(uint64_t) * n * W);
+  float *rows_d = (float *)malloc(sizeof(float) * n * W);
+  for (uint64_t i = 0; i < n * W; i++) {
+    rows[i] = ORC_EMPTY;
+    rows_d[i] = ORC_FMAX;
+  }
+  uint32_t layer_count = ix->layer_count;
+  orc_search_params ips = bp->initial_partition_search;
+
+  /* 1. generate_initial_partitions  src/search.rs:32-71 */
+  uint64_t K = layer_count == 0 ? (n > 1 ? n - 1 : 1) : ips.number_of_candidates;
+  nd_pair *init = (nd_pair *)malloc(sizeof(nd_pair) * n * K);
+  uint64_t *init_len = (uint64_t *)calloc(n, sizeof(uint64_t));
+  int rc_all = 0;
+#pragma omp parallel num_threads(T)
+  {
+    orc_scratch *sc = layer_count ? orc_scratch_new(ix, 0) : NULL;
+    uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * (ips.number_of_candidates + 1));
+    float *od = (float *)malloc(sizeof(float) * (ips.number_of_candidates + 1));
+#pragma omp for schedule(dynamic, 16)
+    for (uint64_t i = 0; i < n; i++) {
+      nd_pair *L = init + i * K;
+      uint64_t m = 0;
+      if (layer_count == 0) {
+        /* compare_all  src/search.rs:13-30 */
+        for (uint64_t j = 0; j < n; j++) {
+          if (vs[j] == vs[i]) continue;
+          nd_pair p = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[j] * (uint64_t)S->ld), j};
+          L[m++] = p;
+        }
+        qsort(L, m, sizeof(nd_pair), nd_cmp); /* ids are node ids; monotone in vector id */
+      } else {
+        /* initial_vector_distances  src/search.rs:73-82 */
+        uint64_t len = 0;
+        int rc = orc_search_sc(ix, NULL, vs[i], ips, 0, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
+        if (rc) {
+#pragma omp atomic write
+          rc_all = rc;
+          len = 0;
+        }
+        for (uint64_t k = 0; k < len; k++) {
+          if (oi[k] == vs[i]) continue; /* filter(|(w,_)| v != *w) */
+          /* NodeId(vs.binary_search(&inner_vector_id).unwrap())  src/search.rs:57-60 */
+          uint64_t *hit = (uint64_t *)bsearch(&oi[k], vs, n, sizeof(uint64_t), u64_cmp);
+          if (!hit) {
+#pragma omp atomic write
+            rc_all = -2;
+            continue;
+          }
+          nd_pair p = {od[k], (uint64_t)(hit - vs)};
+          L[m++] = p;
+        }
+      }
+      init_len[i] = m;
+    }
+    free(oi);
+    free(od);
+    orc_scratch_free(sc);
+  }
+  if (rc_all) {
+    free(vs); free(rows); free(rows_d); free(init); free(init_len);
+    return rc_all;
+  }
+
+  /* 2. partition groups keyed by the nearest super node (src/lib.rs:711-713).  Member
+   * order = the sort of src/search.rs:67-69 (first distance; None first), made total with
+   * the node id. */
+  gm_t *gm = (gm_t *)malloc(sizeof(gm_t) * n);
+  for (uint64_t i = 0; i < n; i++) {
+    gm[i].node = i;
+    if (init_len[i]) {
+      gm[i].key = init[i * K].id;
+      gm[i].d = init[i * K].d;
+    } else {
+      gm[i].key = ORC_EMPTY;
+      gm[i].d = 0.0f;
+    }
+  }
+  qsort(gm, n, sizeof(gm_t), gm_cmp);
+  uint64_t *gstart = (uint64_t *)calloc(n + 1, sizeof(uint64_t)); /* per key node; slot n = None */
+  uint64_t *gsize = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
+  for (uint64_t p = 0; p < n; p++) {
+    uint64_t slot = gm[p].key == ORC_EMPTY ? n : gm[p].key;
+    if (gsize[slot] == 0) gstart[slot] = p;
+    gsize[slot]++;
+  }
+
+  /* 3. neighbourhood seeding  src/lib.rs:719-787 */
+#pragma omp parallel num_threads(T)
+  {
+    uint64_t maxc = W * 5 + K + 8;
+    nd_pair *list = (nd_pair *)malloc(sizeof(nd_pair) * maxc);
+    uint64_t *pstart = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
+    uint64_t *psize = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
+#pragma omp for schedule(dynamic, 16)
+    for (uint64_t i = 0; i < n; i++) {
+      uint64_t m = 0;
+      for (uint64_t k = 0; k < init_len[i]; k++) list[m++] = init[i * K + k]; /* distances.clone() */
+      uint64_t np = 0, total = 0;
+      for (uint64_t k = 0; k < init_len[i]; k++) { /* filter_map(partition_groups.get(Some(n))) */
+        uint64_t s = init[i * K + k].id;
+        if (gsize[s]) {
+          pstart[np] = gstart[s];
+          psize[np] = gsize[s];
+          total += gsize[s];
+          np++;
+        }
+      }
+      if (np == 0) { /* partitions.push(partition) : our own group  :739-742 */
+        uint64_t slot = init_len[i] ? init[i * K].id : n;
+        pstart[0] = gstart[slot];
+        psize[0] = gsize[slot];
+        total = gsize[slot];
+        np = 1;
+      }
+      uint64_t choice_count = W * 5 < total ? W * 5 : total; /* :745-746 */
+      /* choose_n_1 (src/lib.rs:1830-1852; the Exp branch of choose_n :1861-1880 is
+       * unreachable from here because choice_count <= sum(partition_maxes)): all
+       * (partition, index) pairs except (0, exclude=node_id.0), shuffled, truncated. */
+      uint64_t excl = i < psize[0] ? 1 : 0;
+      uint64_t domain = total - excl;
+      uint64_t picks = choice_count < domain ? choice_count : domain;
+      /* StdRng::seed_from_u64(layer_count + vector_id + vs.len())  :729-731 */
+      uint64_t key = orc_mix64((uint64_t)layer_count + vs[i] + n) ^ orc_mix64(bp->seed + 0x632BE59BD9B4E019ULL);
+      for (uint64_t k = 0; k < picks; k++) {
+        uint64_t f = orc_feistel_perm(k, domain, key);
+        if (excl && f >= i) f += 1;
+        uint64_t p = 0;
+        while (f >= psize[p]) {
+          f -= psize[p];
+          p++;
+        }
+        uint64_t member = gm[pstart[p] + f].node;
+        /* compare_vec(Stored(vector_id), Stored(choice.1))  :750-754 */
+        nd_pair c = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[member] * (uint64_t)S->ld), member};
+        list[m++] = c;
+      }
+      finish_row(list, m, i, W, rows + i * W, rows_d + i * W);
+    }
+    free(list);
+    free(pstart);
+    free(psize);
+  }
+
+  /* 4. make neighbourhoods bidirectional  src/lib.rs:789-815 (snapshot form) */
+  uint64_t np = 0;
+  for (uint64_t i = 0; i < n * W; i++)
+    if (rows[i] != ORC_EMPTY) np++;
+  uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
+  uint64_t *ps = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
+  float *pd = (float *)malloc(sizeof(float) * (np ? np : 1));
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < n; i++)
+    for (uint64_t k = 0; k < W; k++)
+      if (rows[i * W + k] != ORC_EMPTY) {
+        pt[c] = rows[i * W + k];
+        ps[c] = i;
+        pd[c] = rows_d[i * W + k];
+        c++;
+      }
+  merge_proposals(n, W, rows, rows_d, pt, ps, pd, np, T);
+  free(pt); free(ps); free(pd);
+
+  orc_index_push_layer(ix, vs, rows, n, W);
+  free(gm); free(gstart); free(gsize); free(init); free(init_len);
+  free(vs); free(rows); free(rows_d);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- link round */
+
+/* link_nodes_in_layer_to_better_neighbors over all nodes  src/lib.rs:1070-1154.
+ * link_count = self.neighborhood_size() (bp.neighborhood_size, also on layer 0: :1093) */
+uint64_t orc_link_layer(orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t link_count,
+                        int threads) {
+  const orc_store *S = &ix->store;
+  orc_layer *L = &ix->layers[lft];
+  uint64_t n = L->node_count, W = L->neighborhood_size;
+  int T = threads > 0 ? threads : 1;
+  uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * n * link_count);
+  float *pd = (float *)malloc(sizeof(float) * n * link_count);
+  uint64_t *pcount = (uint64_t *)calloc(n, sizeof(uint64_t));
+  /* searches run against the unmodified layer (pseudo_layer = clone :1097-1100) */
+#pragma omp parallel num_threads(T)
+  {
+    orc_scratch *sc = orc_scratch_new(ix, 0);
+    uint64_t cap = sp.number_of_candidates;
+    uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    float *od = (float *)malloc(sizeof(float) * cap);
+#pragma omp for schedule(dynamic, 16)
+    for (uint64_t i = 0; i < n; i++) {
+      uint64_t vector = L->nodes[i];
+      uint64_t len = 0;
+      /* search_layers(Stored(vector), sp, &pseudo_stack, Some(vector))  :1112-1117 */
+      orc_search_sc(ix, NULL, vector, sp, lft + 1, vector, oi, od, &len, NULL, sc, NULL);
+      uint64_t m = 0;
+      for (uint64_t k = 0; k < len && k < link_count; k++) { /* take(neighborhood_size) */
+        if (oi[k] == vector) break;                           /* :1119-1121 */
+        pt[i * link_count + m] = orc_layer_get_node(L, oi[k]);
+        pd[i * link_count + m] = od[k];
+        m++;
+      }
+      pcount[i] = m;
+    }
+    free(oi);
+    free(od);
+    orc_scratch_free(sc);
+  }
+  /* distances of the current occupants to the row owner, recomputed as :1128-1133 does */
+  float *rows_d = (float *)malloc(sizeof(float) * n * W);
+#pragma omp parallel for num_threads(T) schedule(dynamic, 64)
+  for (uint64_t t = 0; t < n; t++)
+    for (uint64_t k = 0; k < W; k++) {
+      uint64_t o = L->neighbors[t * W + k];
+      rows_d[t * W + k] = o == ORC_EMPTY ? ORC_FMAX
+                                         : orc_distance(S, S->rows + L->nodes[o] * (uint64_t)S->ld,
+                                                        S->rows + L->nodes[t] * (uint64_t)S->ld);
+    }
+  uint64_t np = 0;
+  for (uint64_t i = 0; i < n; i++) np += pcount[i];
+  uint64_t *ft = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
+  uint64_t *fs = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
+  float *fd = (float *)malloc(sizeof(float) * (np ? np : 1));
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < n; i++)
+    for (uint64_t k = 0; k < pcount[i]; k++) {
+      ft[c] = pt[i * link_count + k];
+      fs[c] = i;
+      fd[c] = pd[i * link_count + k];
+      c++;
+    }
+  uint64_t added = merge_proposals(n, W, L->neighbors, rows_d, ft, fs, fd, np, T);
+  free(ft); free(fs); free(fd); free(rows_d); free(pt); free(pd); free(pcount);
+  return added;
+}
+
+/* ---------------------------------------------------------------- recall / improve */
+
+/* stochastic_recall_at  src/lib.rs:1463-1499 */
+float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_params *op, int threads) {
+  const orc_layer *L = &ix->layers[at];
+  uint64_t total = L->node_count;
+  uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
+  if (selection < 1) selection = 1;
+  if (selection > total) selection = total;
+  uint64_t *vecs = (uint64_t *)malloc(sizeof(uint64_t) * total);
+  memcpy(vecs, L->nodes, sizeof(uint64_t) * total);
+  if (selection != total) orc_shuffle_u64(vecs, total, 42); /* StdRng::seed_from_u64(42) */
+  uint64_t cap = op->search.number_of_candidates;
+  uint64_t relevant = 0;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+    orc_scratch *sc = orc_scratch_new(ix, 0);
+    uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    float *od = (float *)malloc(sizeof(float) * cap);
+#pragma omp for schedule(dynamic, 16) reduction(+ : relevant)
+    for (uint64_t k = 0; k < selection; k++) {
+      uint64_t len = 0;
+      /* self.search(Stored(vid), op.search): the whole stack  :1488-1491 */
+      orc_search_sc(ix, NULL, vecs[k], op->search, 0, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
+      for (uint64_t j = 0; j < len; j++)
+        if (oi[j] == vecs[k]) {
+          relevant++;
+          break;
+        }
+    }
+    free(oi);
+    free(od);
+    orc_scratch_free(sc);
+  }
+  free(vecs);
+  return (float)relevant / (float)selection;
+}
+
+/* improve_neighbors_upto  src/lib.rs:1515-1544 */
+float orc_improve_neighbors_upto(orc_index *ix, uint32_t upto, const orc_build_params *bp,
+                                 float last_recall_or_nan, int threads) {
+  const orc_opt_params *op = &bp->optimization;
+  float last_recall = (last_recall_or_nan != last_recall_or_nan) ? 0.0f : last_recall_or_nan;
+  float last_improvement = 1.0f;
+  uint64_t rounds = 0;
+  while (last_improvement >= op->neighborhood_threshold && last_recall < 1.0f) {
+    for (uint32_t lft = 0; lft < upto; lft++)
+      orc_link_layer(ix, lft, op->search, bp->neighborhood_size, threads);
+    float recall = orc_stochastic_recall_at(ix, upto - 1, op, threads);
+    last_improvement = recall - last_recall;
+    last_recall = recall;
+    rounds++;
+    if (bp->max_link_rounds && rounds >= bp->max_link_rounds) break;
+  }
+  return last_recall;
+}
+
+/* improve_index_at  src/lib.rs:1546-1603 with promote_at_layer treated as "did not
+ * promote" (promotion = SURVEY section 8 row f2, out of scope) */
+static float improve_index_at(orc_index *ix, uint32_t lft, const orc_build_params *bp, int threads) {
+  const orc_opt_params *op = &bp->optimization;
+  float recall = orc_stochastic_recall_at(ix, lft, op, threads);
+  float improvement = 1.0f;
+  int bailout = 1;
+  while (improvement >= op->promotion_threshold && recall < 1.0f && bailout != 0) {
+    float last = recall;
+    uint32_t cur = 0;
+    while (cur <= lft && bailout != 0) {
+      recall = orc_improve_neighbors_upto(ix, cur + 1, bp, NAN, threads);
+      cur++;
+    }
+    bailout--;
+    improvement = recall - last;
+  }
+  return recall;
+}
+
+/* improve_index  src/lib.rs:1664-1686 */
+float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads) {
+  float recall = orc_stochastic_recall_at(ix, ix->layer_count - 1, &bp->optimization, threads);
+  for (uint32_t lft = 0; lft < ix->layer_count; lft++) recall = improve_index_at(ix, lft, bp, threads);
+  return recall;
+}
+
+/* Hnsw::generate  src/lib.rs:825-893 */
+orc_index *orc_generate(const float *rows, uint64_t n_store, uint32_t dim, uint32_t ld, int metric,
+                        int sum_mode, const uint64_t *vids, uint64_t n, const orc_build_params *bp,
+                        int threads) {
+  if (n == 0 || bp->order < 2) return NULL; /* assert!(total_size > 0) :837 */
+  orc_index *ix = orc_index_new(rows, n_store, dim, ld, metric, sum_mode);
+  if (!ix) return NULL;
+  uint64_t *vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  memcpy(vs, vids, sizeof(uint64_t) * n);
+  orc_shuffle_u64(vs, n, bp->seed); /* vs.shuffle(&mut thread_rng()) :832-833 */
+  uint64_t parts[128];
+  uint32_t np = orc_calculate_partitions(n, bp->order, parts, 128);
+  for (uint32_t i = 0; i < np; i++) {
+    uint64_t length = parts[i] < n ? parts[i] : n; /* :858-860 */
+    uint32_t level = np - i - 1;
+    uint64_t W = level == 0 ? bp->zero_layer_neighborhood_size : bp->neighborhood_size;
+    if (orc_generate_layer(ix, vs, length, W, bp, threads)) {
+      orc_index_free(ix);
+      free(vs);
+      return NULL;
+    }
+    orc_improve_index(ix, bp, threads); /* :877 */
+  }
+  free(vs);
+  return ix;
+}
+
+/* assert_layer_invariants  src/search.rs:142-171 */
+int orc_check_layer_invariants(const orc_index *ix) {
+  for (uint32_t i = 0; i < ix->layer_count; i++) {
+    const orc_layer *c = &ix->layers[i];
+    for (uint64_t k = 1; k < c->node_count; k++)
+      if (c->nodes[k] <= c->nodes[k - 1]) return -1;
+    if (i + 1 < ix->layer_count)
+      for (uint64_t k = 0; k < c->node_count; k++)
+        if (orc_layer_get_node(&ix->layers[i + 1], c->nodes[k]) == ORC_EMPTY) return -2;
+  }
+  return 0;
+}
