@@ -1,0 +1,186 @@
+/*
+ * phnsw.h -- C ABI of the MI355X-native HNSW build + search engine.
+ *
+ * Drop-in boundary for ONE hot path of terminusdb-labs/parallel-hnsw (Rust): the per-hop
+ * candidate distance batch and the greedy layer search / layer construction loops around
+ * it.  The reference's seam is the generic, one-pair-per-call trait
+ *     Comparator::{lookup, compare_raw, compare_vec}            src/lib.rs:53-74
+ * which cannot feed a GPU, so this ABI sits one level up, under the method surface of
+ *     Hnsw<C>::{generate, search, search_upto, improve_index, improve_neighbors,
+ *               stochastic_recall, knn, threshold_nn}           src/lib.rs:585-1686
+ * and batches beneath it.  A Rust shim implements `Comparator` for a
+ * store handle and wraps `Hnsw` around an index handle.
+ *
+ * Conventions
+ *  - every entry point returns 0 on success, a negative PHNSW_E_* otherwise, and never
+ *    unwinds; phnsw_last_error() gives the message of the calling thread's last failure.
+ *    (The reference panics: unwrap lib.rs:261, NaN types.rs:86, empty input lib.rs:683,837.)
+ *  - ids are u64 at the boundary like the reference's usize VectorId/NodeId
+ *    (src/types.rs:3-13); PHNSW_EMPTY == !0 is the empty-slot sentinel.
+ *  - host pointers unless the name ends in _device; outputs are caller allocated; the
+ *    library never frees caller memory and copies what it needs before returning.
+ *  - search entry points are thread safe; build / improve entry points need exclusive
+ *    access to their index (lib.rs: &self vs &mut self).
+ *  - there is NO CPU fallback: every call fails with PHNSW_E_NO_DEVICE without a gfx950 GPU.
+ */
+#ifndef PHNSW_H
+#define PHNSW_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHNSW_EMPTY UINT64_MAX /* VectorId::MAX / NodeId::MAX  src/types.rs:8-13 */
+
+enum {
+  PHNSW_OK = 0,
+  PHNSW_E_INVALID = -1,   /* bad argument (the reference would panic/assert) */
+  PHNSW_E_NO_DEVICE = -2, /* no HIP device / wrong architecture */
+  PHNSW_E_HIP = -3,       /* HIP runtime error, see phnsw_last_error */
+  PHNSW_E_MISSING_NODE = -4, /* candidate vector absent from a lower layer (lib.rs:261 unwrap) */
+  PHNSW_E_OVERFLOW = -5,  /* frontier workspace exhausted even after growth */
+  PHNSW_E_NAN = -6,       /* NaN in input vectors (types.rs:86 would panic later) */
+  PHNSW_E_UNSUPPORTED = -7
+};
+
+/* the three Comparator::compare_raw implementations in the reference tree */
+enum {
+  PHNSW_METRIC_COSINE_HALF = 0,   /* (1 - dot)/2        BigComparator, src/bigvec.rs:47-53 */
+  PHNSW_METRIC_ONE_MINUS_DOT = 1, /* 1 - dot            src/lib.rs:1985-1991 */
+  PHNSW_METRIC_L2 = 2             /* sqrt(sum (a-b)^2)  src/lib.rs:2431-2437, src/pq.rs:499-505 */
+};
+
+/* SearchParameters  src/parameters.rs:3-18 (field for field) */
+typedef struct {
+  uint64_t number_of_candidates;
+  uint64_t upper_layer_candidate_count;
+  uint64_t probe_depth;
+} phnsw_search_params;
+
+/* OptimizationParameters  src/parameters.rs:20-40 */
+typedef struct {
+  float promotion_threshold;
+  float neighborhood_threshold;
+  float recall_proportion;
+  float promotion_proportion;
+  phnsw_search_params search;
+} phnsw_optimization_params;
+
+/* BuildParameters  src/parameters.rs:42-64, plus the two knobs that replace the
+ * reference's non-determinism / unbounded loops */
+typedef struct {
+  uint64_t order;
+  uint64_t zero_layer_neighborhood_size;
+  uint64_t neighborhood_size;
+  phnsw_optimization_params optimization;
+  phnsw_search_params initial_partition_search;
+  uint64_t seed;            /* replaces thread_rng() of lib.rs:832 */
+  uint64_t max_link_rounds; /* 0 = loop until improvement < neighborhood_threshold (lib.rs:1527) */
+} phnsw_build_params;
+
+void phnsw_default_search_params(phnsw_search_params *sp);
+void phnsw_default_build_params(phnsw_build_params *bp);
+
+typedef struct phnsw_store phnsw_store; /* vector store + metric == a Comparator */
+typedef struct phnsw_index phnsw_index; /* Hnsw<C> */
+
+/* ProgressMonitor::update / keep_alive  src/progress.rs:12-16: called from the calling
+ * thread between build phases; return non-zero to request an interrupt. */
+typedef int (*phnsw_progress_cb)(void *user, const char *phase, uint64_t done, uint64_t total);
+
+const char *phnsw_last_error(void);
+int phnsw_device_count(void);
+
+/* ---- store: replaces BigComparator{data: Arc<Vec<Vec<f32>>>}  src/bigvec.rs:38-57 ----
+ * rows are copied into one flat HBM array [n][ld], ld = dim rounded up to 4 floats. */
+int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, int metric, int device,
+                       phnsw_store **out);
+/* adopt an existing device array (e.g. a torch tensor); caller keeps it alive */
+int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, uint32_t ld,
+                              int metric, int device, phnsw_store **out);
+/* synthetic rows with the distribution of random_normed_vec (src/bigvec.rs:59-65),
+ * generated on the device: component j of vector i keyed (seed + first + i, j) */
+int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
+                                 int normalize, int metric, int device, phnsw_store **out);
+int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim, uint32_t *ld, int *metric,
+                     const float **rows_dev);
+/* copy rows [first, first+count) back to the host, dim floats each */
+int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t count, float *out);
+void phnsw_store_destroy(phnsw_store *s);
+
+/* Comparator::compare_vec batched  src/lib.rs:69-73: out[i] = d(query, Stored(ids[i])).
+ * query == NULL means AbstractVector::Stored(query_id). */
+int phnsw_distance_batch(const phnsw_store *s, const float *query, uint64_t query_id,
+                         const uint64_t *ids, uint64_t k, float *out);
+
+/* ---- index ---- */
+/* adopt a layer stack built elsewhere (e.g. by the Rust crate); layers top first like
+ * Hnsw.layers (lib.rs:587); nodes sorted ascending; neighbor rows padded with PHNSW_EMPTY */
+int phnsw_index_from_layers(phnsw_store *s, uint32_t layer_count, const uint64_t *node_counts,
+                            const uint64_t *neighborhood_sizes, const uint64_t *const *nodes,
+                            const uint64_t *const *neighbors, phnsw_index **out);
+/* Hnsw::generate  src/lib.rs:825-893 */
+int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                phnsw_progress_cb cb, void *user, phnsw_index **out);
+/* Hnsw::generate_layer appended below the current stack  src/lib.rs:675-823 */
+int phnsw_generate_layer(phnsw_index *ix, const uint64_t *vids, uint64_t n,
+                         uint64_t neighborhood_size, const phnsw_build_params *bp);
+/* link_layer_to_better_neighbors  src/lib.rs:1070-1154 ; *out_added = new edges */
+int phnsw_link_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                     uint64_t link_count, uint64_t *out_added);
+/* Hnsw::improve_index  src/lib.rs:1664-1686 (promotion not performed) */
+int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb,
+                        void *user, float *out_recall);
+/* Hnsw::improve_neighbors_upto  src/lib.rs:1515-1544 ; last_recall NaN = None */
+int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
+                                 float last_recall, float *out_recall);
+/* Hnsw::stochastic_recall_at  src/lib.rs:1463-1499 */
+int phnsw_stochastic_recall_at(phnsw_index *ix, uint32_t layer_from_top,
+                               const phnsw_optimization_params *op, float *out_recall);
+void phnsw_index_destroy(phnsw_index *ix);
+
+uint32_t phnsw_index_layer_count(const phnsw_index *ix);
+/* Layer{neighborhood_size, nodes, neighbors}  src/lib.rs:85-91 */
+int phnsw_index_layer_info(const phnsw_index *ix, uint32_t layer_from_top, uint64_t *node_count,
+                           uint64_t *neighborhood_size);
+int phnsw_index_layer_read(const phnsw_index *ix, uint32_t layer_from_top, uint64_t *nodes,
+                           uint64_t *neighbors);
+
+/* Hnsw::search for a batch  src/lib.rs:663-665 -> src/search.rs:84-140.
+ * queries: nq rows of dim floats (AbstractVector::Unstored).  exclude: NULL or nq ids
+ * (PHNSW_EMPTY = None).  upto_layers: 0 = all (Hnsw::search_upto lib.rs:654-661).
+ * Outputs: [nq][number_of_candidates] ids / distances sorted by (distance, id), padded with
+ * PHNSW_EMPTY / f32::MAX; out_len[q] = valid entries; out_stats (nullable) [nq][2] =
+ * {distance evaluations, hops}. */
+int phnsw_search_batch(const phnsw_index *ix, const float *queries, uint64_t nq,
+                       const phnsw_search_params *sp, uint32_t upto_layers,
+                       const uint64_t *exclude, uint64_t *out_ids, float *out_d,
+                       uint64_t *out_len, uint64_t *out_stats);
+/* same for AbstractVector::Stored(qids[q]) */
+int phnsw_search_batch_stored(const phnsw_index *ix, const uint64_t *qids, uint64_t nq,
+                              const phnsw_search_params *sp, uint32_t upto_layers,
+                              const uint64_t *exclude, uint64_t *out_ids, float *out_d,
+                              uint64_t *out_len, uint64_t *out_stats);
+/* zero-copy form: everything already resident in HBM, u32 ids (0xFFFFFFFF = empty),
+ * queries [nq][ldq] with ldq a multiple of 4 and zero padding, launched on `stream`
+ * (a hipStream_t, NULL = default) without synchronising.  out_stats_dev [nq][2] u32.
+ * Returns after enqueueing; per-query status lands in status_dev[nq] (0 = ok). */
+int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq,
+                              const uint32_t *qids_dev, uint64_t nq, const phnsw_search_params *sp,
+                              uint32_t upto_layers, const uint32_t *exclude_dev,
+                              uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
+                              uint32_t *out_stats_dev, uint32_t *status_dev, void *stream);
+/* timing of the last phnsw_search_batch_device launch on this index measured with HIP
+ * events on its stream: kernel milliseconds */
+int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
+
+/* Hnsw::knn  src/lib.rs:905-928 : bottom layer, out [node_count][k] */
+int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
+              float *out_d, uint64_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+"""ctypes binding of libphnsw.so (include/phnsw.h).  There is no CPU fallback: importing
+works anywhere, but every compute call raises PhnswError without a gfx950 GPU, and loading
+fails loudly when the shared library has not been built (python __graft_entry__.py build)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphnsw.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class PhnswError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("phnsw error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SearchParams(C.Structure):
+    """SearchParameters  (reference src/parameters.rs:3-18)"""
+    _fields_ = [("number_of_candidates", C.c_uint64),
+                ("upper_layer_candidate_count", C.c_uint64),
+                ("probe_depth", C.c_uint64)]
+
+
+class OptimizationParams(C.Structure):
+    """OptimizationParameters  (reference src/parameters.rs:20-40)"""
+    _fields_ = [("promotion_threshold", C.c_float), ("neighborhood_threshold", C.c_float),
+                ("recall_proportion", C.c_float), ("promotion_proportion", C.c_float),
+                ("search", SearchParams)]
+
+
+class BuildParams(C.Structure):
+    """BuildParameters  (reference src/parameters.rs:42-64) + seed / max_link_rounds"""
+    _fields_ = [("order", C.c_uint64), ("zero_layer_neighborhood_size", C.c_uint64),
+                ("neighborhood_size", C.c_uint64), ("optimization", OptimizationParams),
+                ("initial_partition_search", SearchParams), ("seed", C.c_uint64),
+                ("max_link_rounds", C.c_uint64)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64)
+
+# name -> (restype, argtypes): every symbol include/phnsw.h declares
+_vp, _u64, _u32, _i32, _f32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "phnsw_default_search_params": (None, [C.POINTER(SearchParams)]),
+    "phnsw_default_build_params": (None, [C.POINTER(BuildParams)]),
+    "phnsw_last_error": (C.c_char_p, []),
+    "phnsw_device_count": (_i32, []),
+    "phnsw_store_create": (_i32, [_vp, _u64, _u32, _i32, _i32, _pp]),
+    "phnsw_store_create_device": (_i32, [_vp, _u64, _u32, _u32, _i32, _i32, _pp]),
+    "phnsw_store_create_synthetic": (_i32, [_u64, _u64, _u32, _u64, _i32, _i32, _i32, _pp]),
+    "phnsw_store_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_i32), _pp]),
+    "phnsw_store_read": (_i32, [_vp, _u64, _u64, _vp]),
+    "phnsw_store_destroy": (None, [_vp]),
+    "phnsw_distance_batch": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp]),
+    "phnsw_index_from_layers": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _pp]),
+    "phnsw_build": (_i32, [_vp, _vp, _u64, C.POINTER(BuildParams), _vp, _vp, _pp]),
+    "phnsw_generate_layer": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams)]),
+    "phnsw_link_layer": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, C.POINTER(_u64)]),
+    "phnsw_improve_index": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, C.POINTER(_f32)]),
+    "phnsw_improve_neighbors_upto": (_i32, [_vp, _u32, C.POINTER(BuildParams), _f32, C.POINTER(_f32)]),
+    "phnsw_stochastic_recall_at": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), C.POINTER(_f32)]),
+    "phnsw_index_destroy": (None, [_vp]),
+    "phnsw_index_layer_count": (_u32, [_vp]),
+    "phnsw_index_layer_info": (_i32, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "phnsw_index_layer_read": (_i32, [_vp, _u32, _vp, _vp]),
+    "phnsw_search_batch": (_i32, [_vp, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp, _vp, _vp]),
+    "phnsw_search_batch_stored": (_i32, [_vp, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp, _vp, _vp]),
+    "phnsw_search_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp]),
+    "phnsw_last_search_kernel_ms": (_i32, [_vp, C.POINTER(_f32)]),
+    "phnsw_knn": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build_lib(force=False):
+    """hipcc --offload-arch=gfx950 the HIP sources into parallel_hnsw_amd/libphnsw.so"""
+    args = ["make", "-C", CSRC, "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libphnsw.so is not built (run `python __graft_entry__.py` or "
+                              "`make -C parallel_hnsw_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().phnsw_last_error()
+        raise PhnswError(rc, msg.decode() if msg else "")

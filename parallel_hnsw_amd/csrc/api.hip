@@ -1,0 +1,706 @@
+// C ABI of libphnsw (include/phnsw.h): handles, transfers, launches.  Host-side logic
+// only -- all arithmetic on vectors and all graph traversal happens in the gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "phnsw_internal.h"
+
+static thread_local std::string g_err;
+
+void ph_set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+int ph_hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  ph_set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? PHNSW_E_NO_DEVICE : PHNSW_E_HIP;
+}
+
+extern "C" const char *phnsw_last_error(void) { return g_err.c_str(); }
+
+extern "C" int phnsw_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" void phnsw_default_search_params(phnsw_search_params *sp) {
+  // SearchParameters::default  src/parameters.rs:10-18
+  sp->number_of_candidates = 300;
+  sp->upper_layer_candidate_count = 300;
+  sp->probe_depth = 2;
+}
+
+extern "C" void phnsw_default_build_params(phnsw_build_params *bp) {
+  // BuildParameters::default  src/parameters.rs:50-64
+  bp->order = 12;
+  bp->zero_layer_neighborhood_size = 48;
+  bp->neighborhood_size = 24;
+  bp->optimization.promotion_threshold = 0.01f;
+  bp->optimization.neighborhood_threshold = 0.01f;
+  bp->optimization.recall_proportion = 0.1f;
+  bp->optimization.promotion_proportion = 1.0f;
+  phnsw_default_search_params(&bp->optimization.search);
+  bp->initial_partition_search.number_of_candidates = 6;
+  bp->initial_partition_search.upper_layer_candidate_count = 6;
+  bp->initial_partition_search.probe_depth = 2;
+  bp->seed = 0;
+  bp->max_link_rounds = 0;
+}
+
+static int use_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    ph_set_error("no HIP device available (libphnsw has no CPU fallback)");
+    return PHNSW_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    ph_set_error("device %d out of range (%d devices)", device, n);
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(device));
+  return 0;
+}
+
+// ------------------------------------------------------------------ store
+
+static int store_check_nan(phnsw_store *s) {
+  uint32_t *cnt = nullptr;
+  PH_HIP(hipMalloc(&cnt, 4));
+  PH_HIP(hipMemset(cnt, 0, 4));
+  int rc = ph_count_nan(s->rows, s->n * (uint64_t)s->ld, cnt, 0);
+  uint32_t h = 0;
+  if (!rc) {
+    hipError_t e = hipMemcpy(&h, cnt, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "memcpy nan count", __FILE__, __LINE__);
+  }
+  hipFree(cnt);
+  if (rc) return rc;
+  if (h) {
+    ph_set_error("%u NaN components in the vector store (OrderedFloat would panic, types.rs:86)", h);
+    return PHNSW_E_NAN;
+  }
+  return 0;
+}
+
+extern "C" int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, int metric, int device,
+                                  phnsw_store **out) {
+  if (!out || !rows || dim == 0 || n == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
+    ph_set_error("phnsw_store_create: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  int rc = use_device(device);
+  if (rc) return rc;
+  phnsw_store *s = new phnsw_store();
+  s->device = device;
+  s->n = n;
+  s->dim = dim;
+  s->ld = (dim + 3) / 4 * 4;
+  s->metric = metric;
+  hipError_t e = hipMalloc(&s->rows, (size_t)n * s->ld * 4);
+  if (e != hipSuccess) {
+    delete s;
+    return ph_hip_fail(e, "hipMalloc store", __FILE__, __LINE__);
+  }
+  if (s->ld == dim)
+    e = hipMemcpy(s->rows, rows, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+  else {
+    e = hipMemset(s->rows, 0, (size_t)n * s->ld * 4);
+    if (e == hipSuccess)
+      e = hipMemcpy2D(s->rows, (size_t)s->ld * 4, rows, (size_t)dim * 4, (size_t)dim * 4, n, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    hipFree(s->rows);
+    delete s;
+    return ph_hip_fail(e, "copy store", __FILE__, __LINE__);
+  }
+  rc = store_check_nan(s);
+  if (rc) {
+    hipFree(s->rows);
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, uint32_t ld, int metric,
+                                         int device, phnsw_store **out) {
+  if (!out || !rows_dev || dim == 0 || n == 0 || ld < dim || (ld % 4) || metric < 0 || metric > 2 ||
+      n >= 0x7FFFFFFFull || ((uintptr_t)rows_dev % 16)) {
+    ph_set_error("phnsw_store_create_device: invalid argument (ld must be a multiple of 4 >= dim, base 16-byte aligned)");
+    return PHNSW_E_INVALID;
+  }
+  int rc = use_device(device);
+  if (rc) return rc;
+  phnsw_store *s = new phnsw_store();
+  s->device = device;
+  s->rows = const_cast<float *>(rows_dev);
+  s->owns_rows = false;
+  s->n = n;
+  s->dim = dim;
+  s->ld = ld;
+  s->metric = metric;
+  rc = store_check_nan(s);
+  if (rc) {
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed, int normalize,
+                                            int metric, int device, phnsw_store **out) {
+  if (!out || dim == 0 || n == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
+    ph_set_error("phnsw_store_create_synthetic: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  int rc = use_device(device);
+  if (rc) return rc;
+  phnsw_store *s = new phnsw_store();
+  s->device = device;
+  s->n = n;
+  s->dim = dim;
+  s->ld = (dim + 3) / 4 * 4;
+  s->metric = metric;
+  hipError_t e = hipMalloc(&s->rows, (size_t)n * s->ld * 4);
+  if (e != hipSuccess) {
+    delete s;
+    return ph_hip_fail(e, "hipMalloc store", __FILE__, __LINE__);
+  }
+  rc = ph_synth_rows(s->rows, first, n, dim, s->ld, seed, normalize, 0);
+  if (!rc) {
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = ph_hip_fail(e, "synth sync", __FILE__, __LINE__);
+  }
+  if (rc) {
+    hipFree(s->rows);
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim, uint32_t *ld, int *metric,
+                                const float **rows_dev) {
+  if (!s) return PHNSW_E_INVALID;
+  if (n) *n = s->n;
+  if (dim) *dim = s->dim;
+  if (ld) *ld = s->ld;
+  if (metric) *metric = s->metric;
+  if (rows_dev) *rows_dev = s->rows;
+  return 0;
+}
+
+extern "C" int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t count, float *out) {
+  if (!s || !out || first + count > s->n) {
+    ph_set_error("phnsw_store_read: range out of bounds");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  if (count == 0) return 0;
+  PH_HIP(hipMemcpy2D(out, (size_t)s->dim * 4, s->rows + first * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4, count,
+                     hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" void phnsw_store_destroy(phnsw_store *s) {
+  if (!s) return;
+  if (--s->refcount > 0) return;
+  hipSetDevice(s->device);
+  if (s->owns_rows && s->rows) hipFree(s->rows);
+  delete s;
+}
+
+extern "C" int phnsw_distance_batch(const phnsw_store *s, const float *query, uint64_t query_id, const uint64_t *ids,
+                                    uint64_t k, float *out) {
+  if (!s || !ids || !out || (!query && query_id >= s->n) || k > 0xFFFFFFFFull) {
+    ph_set_error("phnsw_distance_batch: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  if (k == 0) return 0;
+  PH_HIP(hipSetDevice(s->device));
+  std::vector<uint32_t> ids32(k);
+  for (uint64_t i = 0; i < k; i++) ids32[i] = ids[i] >= s->n ? PH_EMPTY32 : (uint32_t)ids[i];
+  float *qd = nullptr, *od = nullptr;
+  uint32_t *idd = nullptr;
+  int rc = 0;
+  hipError_t e;
+  std::vector<float> qpad;
+  const float *qsrc = nullptr;
+  if (query) {
+    qpad.assign(s->ld, 0.f);
+    memcpy(qpad.data(), query, (size_t)s->dim * 4);
+    if ((e = hipMalloc(&qd, (size_t)s->ld * 4)) != hipSuccess) return ph_hip_fail(e, "malloc", __FILE__, __LINE__);
+    e = hipMemcpy(qd, qpad.data(), (size_t)s->ld * 4, hipMemcpyHostToDevice);
+    qsrc = qd;
+  } else {
+    qsrc = s->rows + query_id * s->ld;
+    e = hipSuccess;
+  }
+  if (e == hipSuccess) e = hipMalloc(&idd, k * 4);
+  if (e == hipSuccess) e = hipMalloc(&od, k * 4);
+  if (e == hipSuccess) e = hipMemcpy(idd, ids32.data(), k * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) rc = ph_hip_fail(e, "distance_batch setup", __FILE__, __LINE__);
+  if (!rc) rc = ph_distance_batch(s, qsrc, idd, (uint32_t)k, od, 0);
+  if (!rc) {
+    e = hipMemcpy(out, od, k * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "distance_batch copy", __FILE__, __LINE__);
+  }
+  if (qd) hipFree(qd);
+  if (idd) hipFree(idd);
+  if (od) hipFree(od);
+  return rc;
+}
+
+// ------------------------------------------------------------------ index
+
+void ph_layer_free(PhLayerHost &l) {
+  if (l.nodes) hipFree(l.nodes);
+  if (l.neighbors) hipFree(l.neighbors);
+  if (l.nbr_dist) hipFree(l.nbr_dist);
+  if (l.vec2node) hipFree(l.vec2node);
+  l = PhLayerHost();
+}
+
+// upload one layer (u32 device form) and derive the VectorId -> NodeId map that replaces
+// Layer::get_node's binary search (src/lib.rs:129-131)
+int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
+                    PhLayerHost *out) {
+  PhLayerHost l;
+  l.n_nodes = n;
+  l.W = W;
+  hipError_t e = hipMalloc(&l.nodes, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(&l.neighbors, (size_t)n * W * 4);
+  if (e == hipSuccess) e = hipMemcpy(l.nodes, nodes, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(l.neighbors, neighbors, (size_t)n * W * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ph_layer_free(l);
+    return ph_hip_fail(e, "layer upload", __FILE__, __LINE__);
+  }
+  bool identity = true;
+  for (uint32_t i = 0; i < n; i++)
+    if (nodes[i] != i) {
+      identity = false;
+      break;
+    }
+  l.identity = identity;
+  if (!identity) {
+    e = hipMalloc(&l.vec2node, (size_t)ix->store->n * 4);
+    if (e != hipSuccess) {
+      ph_layer_free(l);
+      return ph_hip_fail(e, "vec2node alloc", __FILE__, __LINE__);
+    }
+    int rc = ph_fill_u32(l.vec2node, PH_EMPTY32, ix->store->n, 0);
+    if (!rc) rc = ph_scatter_vec2node(l.nodes, n, l.vec2node, 0);
+    if (!rc) {
+      e = hipDeviceSynchronize();
+      if (e != hipSuccess) rc = ph_hip_fail(e, "vec2node sync", __FILE__, __LINE__);
+    }
+    if (rc) {
+      ph_layer_free(l);
+      return rc;
+    }
+  }
+  *out = l;
+  return 0;
+}
+
+static int validate_layer(const phnsw_store *s, const uint64_t *nodes, const uint64_t *neighbors, uint64_t n,
+                          uint64_t W, std::vector<uint32_t> &nodes32, std::vector<uint32_t> &nb32) {
+  if (n == 0 || W == 0 || W > 64 || n >= 0x7FFFFFFFull) {
+    ph_set_error("layer shape unsupported: node_count=%llu neighborhood_size=%llu (1..64)", (unsigned long long)n,
+                 (unsigned long long)W);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  nodes32.resize(n);
+  nb32.resize(n * W);
+  for (uint64_t i = 0; i < n; i++) {
+    if (nodes[i] >= s->n || (i > 0 && nodes[i] <= nodes[i - 1])) {
+      ph_set_error("layer nodes must be strictly increasing VectorIds below the store size (search.rs:150-157)");
+      return PHNSW_E_INVALID;
+    }
+    nodes32[i] = (uint32_t)nodes[i];
+  }
+  for (uint64_t i = 0; i < n; i++) {
+    bool ended = false;
+    for (uint64_t k = 0; k < W; k++) {
+      uint64_t v = neighbors[i * W + k];
+      if (v == PHNSW_EMPTY) {
+        ended = true;
+        nb32[i * W + k] = PH_EMPTY32;
+        continue;
+      }
+      if (ended || v >= n) {
+        ph_set_error("neighbor row %llu: ids must be < node_count and sentinels trailing only (lib.rs:108-125)",
+                     (unsigned long long)i);
+        return PHNSW_E_INVALID;
+      }
+      for (uint64_t j = 0; j < k; j++)
+        if (neighbors[i * W + j] == v) {
+          ph_set_error("neighbor row %llu holds node %llu twice; rows must be duplicate free", (unsigned long long)i,
+                       (unsigned long long)v);
+          return PHNSW_E_INVALID;
+        }
+      nb32[i * W + k] = (uint32_t)v;
+    }
+  }
+  return 0;
+}
+
+extern "C" int phnsw_index_from_layers(phnsw_store *s, uint32_t layer_count, const uint64_t *node_counts,
+                                       const uint64_t *neighborhood_sizes, const uint64_t *const *nodes,
+                                       const uint64_t *const *neighbors, phnsw_index **out) {
+  if (!s || !out || layer_count == 0 || layer_count > PH_MAX_LAYERS || !node_counts || !neighborhood_sizes ||
+      !nodes || !neighbors) {
+    ph_set_error("phnsw_index_from_layers: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  phnsw_index *ix = new phnsw_index();
+  ix->store = s;
+  s->refcount++;
+  phnsw_default_build_params(&ix->bp);
+  for (uint32_t l = 0; l < layer_count; l++) {
+    std::vector<uint32_t> n32, nb32;
+    int rc = validate_layer(s, nodes[l], neighbors[l], node_counts[l], neighborhood_sizes[l], n32, nb32);
+    PhLayerHost lh;
+    if (!rc) rc = ph_layer_upload(ix, n32.data(), nb32.data(), (uint32_t)node_counts[l], (uint32_t)neighborhood_sizes[l], &lh);
+    if (rc) {
+      phnsw_index_destroy(ix);
+      return rc;
+    }
+    ix->layers.push_back(lh);
+  }
+  *out = ix;
+  return 0;
+}
+
+extern "C" void phnsw_index_destroy(phnsw_index *ix) {
+  if (!ix) return;
+  hipSetDevice(ix->store->device);
+  for (auto &l : ix->layers) ph_layer_free(l);
+  ph_workspace_free(ix->ws);
+  phnsw_store_destroy(ix->store);
+  delete ix;
+}
+
+extern "C" uint32_t phnsw_index_layer_count(const phnsw_index *ix) { return ix ? (uint32_t)ix->layers.size() : 0; }
+
+extern "C" int phnsw_index_layer_info(const phnsw_index *ix, uint32_t lft, uint64_t *node_count, uint64_t *W) {
+  if (!ix || lft >= ix->layers.size()) {
+    ph_set_error("layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  if (node_count) *node_count = ix->layers[lft].n_nodes;
+  if (W) *W = ix->layers[lft].W;
+  return 0;
+}
+
+extern "C" int phnsw_index_layer_read(const phnsw_index *ix, uint32_t lft, uint64_t *nodes, uint64_t *neighbors) {
+  if (!ix || lft >= ix->layers.size()) {
+    ph_set_error("layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(ix->store->device));
+  const PhLayerHost &l = ix->layers[lft];
+  if (nodes) {
+    std::vector<uint32_t> t(l.n_nodes);
+    PH_HIP(hipMemcpy(t.data(), l.nodes, (size_t)l.n_nodes * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < l.n_nodes; i++) nodes[i] = t[i];
+  }
+  if (neighbors) {
+    std::vector<uint32_t> t((size_t)l.n_nodes * l.W);
+    PH_HIP(hipMemcpy(t.data(), l.neighbors, t.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < t.size(); i++) neighbors[i] = t[i] == PH_EMPTY32 ? PHNSW_EMPTY : t[i];
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ search
+
+static int check_sp(const phnsw_index *ix, const phnsw_search_params *sp) {
+  if (!ix || !sp || ix->layers.empty()) {
+    ph_set_error("search: null index/params or index without layers");
+    return PHNSW_E_INVALID;
+  }
+  if (sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0 ||
+      sp->probe_depth > 0xFFFFFFFFull) {
+    ph_set_error("search: number_of_candidates must be 1..1024 and probe_depth >= 1 (got %llu, %llu)",
+                 (unsigned long long)sp->number_of_candidates, (unsigned long long)sp->probe_depth);
+    return PHNSW_E_INVALID;
+  }
+  return 0;
+}
+
+static void fill_args(const phnsw_index *ix, const phnsw_search_params *sp, uint32_t upto, PhSearchArgs &a) {
+  memset(&a, 0, sizeof(a));
+  const phnsw_store *s = ix->store;
+  a.vecs = s->rows;
+  a.ld = s->ld;
+  a.nv4 = s->ld / 4;
+  a.metric = s->metric;
+  uint32_t nl = (upto == 0 || upto > ix->layers.size()) ? (uint32_t)ix->layers.size() : upto;
+  a.n_layers = nl;
+  for (uint32_t l = 0; l < nl; l++) {
+    const PhLayerHost &h = ix->layers[l];
+    a.layers[l].n_nodes = h.n_nodes;
+    a.layers[l].W = h.W;
+    a.layers[l].nodes = h.nodes;
+    a.layers[l].neighbors = h.neighbors;
+    a.layers[l].vec2node = h.identity ? nullptr : h.vec2node;
+  }
+  a.ef = (uint32_t)sp->number_of_candidates;
+  a.upper = (uint32_t)std::min<uint64_t>(sp->upper_layer_candidate_count, 0xFFFFFFFFull);
+  a.probe_depth = (uint32_t)sp->probe_depth;
+}
+
+static uint32_t default_ovf_cap(uint32_t ef) { return std::max<uint32_t>(8192u, ef * 64u); }
+
+// enqueue one search launch; caller owns all device buffers
+int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
+                     uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
+                     uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
+                     uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream) {
+  phnsw_index *mix = const_cast<phnsw_index *>(ix);
+  PhSearchArgs a;
+  fill_args(ix, sp, upto, a);
+  a.queries = queries_dev;
+  a.ldq = ldq;
+  a.qids = qids_dev;
+  a.exclude = exclude_dev;
+  a.nq = (uint32_t)nq;
+  a.out_ids = out_ids;
+  a.out_d = out_d;
+  a.out_len = out_len;
+  a.out_stats = out_stats;
+  a.status = status;
+  a.knn_mode = knn_mode;
+  std::lock_guard<std::mutex> g(mix->ws_mutex);
+  int rc = ph_workspace_ensure(ix, mix->ws, a.ef, ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
+  if (rc) return rc;
+  return ph_search_launch(ix, mix->ws, a, stream);
+}
+
+extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq,
+                                         const uint32_t *qids_dev, uint64_t nq, const phnsw_search_params *sp,
+                                         uint32_t upto_layers, const uint32_t *exclude_dev, uint32_t *out_ids_dev,
+                                         float *out_d_dev, uint32_t *out_len_dev, uint32_t *out_stats_dev,
+                                         uint32_t *status_dev, void *stream) {
+  int rc = check_sp(ix, sp);
+  if (rc) return rc;
+  if ((!queries_dev && !qids_dev) || !out_ids_dev || !out_d_dev || !out_len_dev || !status_dev ||
+      nq > 0xFFFFFFFFull || (queries_dev && (ldq < ix->store->ld || (ldq % 4) || ((uintptr_t)queries_dev % 16)))) {
+    ph_set_error("phnsw_search_batch_device: invalid argument (queries need ldq >= store ld, multiple of 4, 16-byte base)");
+    return PHNSW_E_INVALID;
+  }
+  if (nq == 0) return 0;
+  PH_HIP(hipSetDevice(ix->store->device));
+  return ph_search_device(ix, queries_dev, ldq, qids_dev, nq, sp, upto_layers, exclude_dev, out_ids_dev, out_d_dev,
+                          out_len_dev, out_stats_dev, status_dev, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
+  if (!ix || !ms) return PHNSW_E_INVALID;
+  phnsw_index *mix = const_cast<phnsw_index *>(ix);
+  std::lock_guard<std::mutex> g(mix->ws_mutex);
+  if (!mix->ws.timed) {
+    ph_set_error("no search has been launched on this index");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipEventSynchronize(mix->ws.ev1));
+  PH_HIP(hipEventElapsedTime(ms, mix->ws.ev0, mix->ws.ev1));
+  return 0;
+}
+
+// host-pointer search: stage, launch, grow the spill workspace and retry the few queries
+// that overflowed it, convert u32 -> u64 ids
+static int search_host(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,
+                       const phnsw_search_params *sp, uint32_t upto, const uint64_t *exclude, uint64_t *out_ids,
+                       float *out_d, uint64_t *out_len, uint64_t *out_stats, uint32_t knn_mode) {
+  int rc = check_sp(ix, sp);
+  if (rc) return rc;
+  if ((!queries && !qids && !knn_mode) || !out_ids || !out_d || !out_len || nq > 0xFFFFFFFFull) {
+    ph_set_error("search: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  if (nq == 0) return 0;
+  const phnsw_store *s = ix->store;
+  PH_HIP(hipSetDevice(s->device));
+  const uint32_t ef = (uint32_t)sp->number_of_candidates;
+  float *qd = nullptr, *od = nullptr;
+  uint32_t *qidd = nullptr, *exd = nullptr, *oid = nullptr, *old_ = nullptr, *ost = nullptr, *std_ = nullptr;
+  hipError_t e = hipSuccess;
+  auto cleanup = [&]() {
+    if (qd) hipFree(qd);
+    if (od) hipFree(od);
+    if (qidd) hipFree(qidd);
+    if (exd) hipFree(exd);
+    if (oid) hipFree(oid);
+    if (old_) hipFree(old_);
+    if (ost) hipFree(ost);
+    if (std_) hipFree(std_);
+  };
+  if (queries) {
+    e = hipMalloc(&qd, (size_t)nq * s->ld * 4);
+    if (e == hipSuccess && s->ld != s->dim) e = hipMemset(qd, 0, (size_t)nq * s->ld * 4);
+    if (e == hipSuccess)
+      e = hipMemcpy2D(qd, (size_t)s->ld * 4, queries, (size_t)s->dim * 4, (size_t)s->dim * 4, nq, hipMemcpyHostToDevice);
+  } else if (qids) {
+    std::vector<uint32_t> t(nq);
+    for (uint64_t i = 0; i < nq; i++) {
+      if (qids[i] >= s->n) {
+        ph_set_error("search: stored query id %llu out of range", (unsigned long long)qids[i]);
+        return PHNSW_E_INVALID;
+      }
+      t[i] = (uint32_t)qids[i];
+    }
+    e = hipMalloc(&qidd, nq * 4);
+    if (e == hipSuccess) e = hipMemcpy(qidd, t.data(), nq * 4, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && exclude) {
+    std::vector<uint32_t> t(nq);
+    for (uint64_t i = 0; i < nq; i++) t[i] = exclude[i] >= s->n ? PH_EMPTY32 : (uint32_t)exclude[i];
+    e = hipMalloc(&exd, nq * 4);
+    if (e == hipSuccess) e = hipMemcpy(exd, t.data(), nq * 4, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipMalloc(&oid, (size_t)nq * ef * 4);
+  if (e == hipSuccess) e = hipMalloc(&od, (size_t)nq * ef * 4);
+  if (e == hipSuccess) e = hipMalloc(&old_, nq * 4);
+  if (e == hipSuccess) e = hipMalloc(&ost, nq * 8);
+  if (e == hipSuccess) e = hipMalloc(&std_, nq * 4);
+  if (e != hipSuccess) {
+    cleanup();
+    return ph_hip_fail(e, "search staging", __FILE__, __LINE__);
+  }
+  uint32_t ovf_cap = default_ovf_cap(ef);
+  rc = ph_search_device(ix, qd, s->ld, qidd, nq, sp, upto, exd, oid, od, old_, ost, std_, ovf_cap, knn_mode, 0);
+  std::vector<uint32_t> h_ids((size_t)nq * ef), h_len(nq), h_st(nq * 2), h_status(nq);
+  std::vector<float> h_d((size_t)nq * ef);
+  if (!rc) {
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_ids.data(), oid, h_ids.size() * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_d.data(), od, h_d.size() * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_len.data(), old_, nq * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_st.data(), ost, nq * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_status.data(), std_, nq * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "search readback", __FILE__, __LINE__);
+  }
+  // queries whose frontier spill outgrew the workspace: rerun them alone with 8x the room
+  for (int attempt = 0; !rc && attempt < 4; attempt++) {
+    std::vector<uint32_t> redo;
+    for (uint64_t i = 0; i < nq; i++) {
+      if (h_status[i] == 4) {
+        ph_set_error("search: a candidate vector is missing from a lower layer (layers not nested, lib.rs:261)");
+        rc = PHNSW_E_MISSING_NODE;
+        break;
+      }
+      if (h_status[i] == 5) redo.push_back((uint32_t)i);
+    }
+    if (rc || redo.empty()) break;
+    if (attempt == 3) {
+      ph_set_error("search: frontier spill exceeded %u entries for %zu queries", ovf_cap, redo.size());
+      rc = PHNSW_E_OVERFLOW;
+      break;
+    }
+    if (knn_mode) {
+      ph_set_error("knn: frontier spill exceeded %u entries", ovf_cap);
+      rc = PHNSW_E_OVERFLOW;
+      break;
+    }
+    ovf_cap *= 8;
+    for (uint32_t qi : redo) {
+      // one query per launch keeps this rare path simple
+      rc = ph_search_device(ix, qd ? qd + (size_t)qi * s->ld : nullptr, s->ld, qidd ? qidd + qi : nullptr, 1, sp, upto,
+                            exd ? exd + qi : nullptr, oid + (size_t)qi * ef, od + (size_t)qi * ef, old_ + qi,
+                            ost + 2 * (size_t)qi, std_ + qi, ovf_cap, 0, 0);
+      if (rc) break;
+      e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipMemcpy(&h_ids[(size_t)qi * ef], oid + (size_t)qi * ef, ef * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(&h_d[(size_t)qi * ef], od + (size_t)qi * ef, ef * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(&h_len[qi], old_ + qi, 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(&h_st[2 * (size_t)qi], ost + 2 * (size_t)qi, 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(&h_status[qi], std_ + qi, 4, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) {
+        rc = ph_hip_fail(e, "search retry readback", __FILE__, __LINE__);
+        break;
+      }
+    }
+  }
+  cleanup();
+  if (rc) return rc;
+  for (size_t i = 0; i < h_ids.size(); i++) out_ids[i] = h_ids[i] == PH_EMPTY32 ? PHNSW_EMPTY : h_ids[i];
+  memcpy(out_d, h_d.data(), h_d.size() * 4);
+  for (uint64_t i = 0; i < nq; i++) out_len[i] = h_len[i];
+  if (out_stats)
+    for (uint64_t i = 0; i < 2 * nq; i++) out_stats[i] = h_st[i];
+  return 0;
+}
+
+extern "C" int phnsw_search_batch(const phnsw_index *ix, const float *queries, uint64_t nq,
+                                  const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
+                                  uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+  if (!queries && nq) {
+    ph_set_error("phnsw_search_batch: queries is NULL");
+    return PHNSW_E_INVALID;
+  }
+  return search_host(ix, queries, nullptr, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
+}
+
+extern "C" int phnsw_search_batch_stored(const phnsw_index *ix, const uint64_t *qids, uint64_t nq,
+                                         const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
+                                         uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+  if (!qids && nq) {
+    ph_set_error("phnsw_search_batch_stored: qids is NULL");
+    return PHNSW_E_INVALID;
+  }
+  return search_host(ix, nullptr, qids, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
+}
+
+// Hnsw::knn  src/lib.rs:905-928: queue of 3k seeded with (self, 0.0), closest_nodes on the
+// bottom layer, drop self, take k
+extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids, float *out_d,
+                         uint64_t *out_len) {
+  if (!ix || ix->layers.empty() || k == 0 || k * 3 > 1024) {
+    ph_set_error("phnsw_knn: k must be 1..341");
+    return PHNSW_E_INVALID;
+  }
+  const PhLayerHost &L = ix->layers.back();
+  phnsw_search_params sp = {k * 3, k * 3, probe_depth};
+  uint64_t n = L.n_nodes, cap = k * 3;
+  std::vector<uint64_t> ids(n * cap), len(n);
+  std::vector<float> d(n * cap);
+  int rc = search_host(ix, nullptr, nullptr, n, &sp, 0, nullptr, ids.data(), d.data(), len.data(), nullptr, 1);
+  if (rc) return rc;
+  std::vector<uint64_t> nodes(n);
+  rc = phnsw_index_layer_read(ix, (uint32_t)ix->layers.size() - 1, nodes.data(), nullptr);
+  if (rc) return rc;
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t o = 0;
+    for (uint64_t j = 0; j < len[i] && o < k; j++) {
+      if (ids[i * cap + j] == nodes[i]) continue;  // filter(|(n,_)| *n != node)
+      out_ids[i * k + o] = ids[i * cap + j];
+      out_d[i * k + o] = d[i * cap + j];
+      o++;
+    }
+    out_len[i] = o;
+    for (; o < k; o++) {
+      out_ids[i * k + o] = PHNSW_EMPTY;
+      out_d[i * k + o] = PH_FMAX;
+    }
+  }
+  return 0;
+}

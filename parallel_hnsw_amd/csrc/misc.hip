@@ -1,0 +1,133 @@
+// Small gfx950 kernels around the search: K1 distance batch (Comparator::compare_vec
+// batched, /root/reference/src/lib.rs:69-73), synthetic data (bigvec.rs:59-65
+// distribution), id-map scatter, NaN scan.
+#include <hip/hip_runtime.h>
+
+#include "phnsw_device.h"
+
+// ---- K1: out[i] = compare_vec(query, Stored(ids[i])); one wave per candidate row ----
+template <int NV>
+__global__ __launch_bounds__(256) void ph_distance_batch_kernel(const float *__restrict__ vecs, uint32_t ld,
+                                                                uint32_t nv4, int metric,
+                                                                const float *__restrict__ query,
+                                                                const uint32_t *__restrict__ ids, uint32_t k,
+                                                                uint64_t n_store, float *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 qv[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    uint32_t c = lane + 64u * j;
+    qv[j] = (c < nv4) ? ((const float4 *)query)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool l2 = metric == PHNSW_METRIC_L2;
+  for (uint32_t i = wave; i < k; i += nwaves) {
+    uint32_t id = ids[i];
+    float d = PH_FMAX;
+    if (id < n_store) {
+      float r = wave_sum(row_partial<NV>((const float4 *)(vecs + (uint64_t)id * ld), qv, nv4, lane, l2));
+      d = finalize_metric(r, metric);
+    }
+    if (lane == 0) out[i] = d;
+  }
+}
+
+int ph_distance_batch(const phnsw_store *st, const float *q_dev, const uint32_t *ids_dev, uint32_t k,
+                      float *out_dev, hipStream_t s) {
+  if (k == 0) return 0;
+  uint32_t nv4 = st->ld / 4;
+  uint32_t blocks = std::min<uint32_t>((k + 3) / 4, 2048);
+#define PH_LAUNCH(NV)                                                                                      \
+  hipLaunchKernelGGL(ph_distance_batch_kernel<NV>, dim3(blocks), dim3(256), 0, s, st->rows, st->ld, nv4,  \
+                     st->metric, q_dev, ids_dev, k, st->n, out_dev)
+  if (nv4 <= 64)
+    PH_LAUNCH(1);
+  else if (nv4 <= 192)
+    PH_LAUNCH(3);
+  else if (nv4 <= 384)
+    PH_LAUNCH(6);
+  else {
+    ph_set_error("dim %u unsupported (max 1536)", st->dim);
+    return PHNSW_E_UNSUPPORTED;
+  }
+#undef PH_LAUNCH
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- synthetic rows: one thread per vector, sequential f32 norm like bigvec.rs:59-65 ----
+__device__ __forceinline__ float ph_synth_component(uint64_t key, uint32_t j) {
+  uint64_t x = ph_mix64(key * 0x9E3779B97F4A7C15ULL + ((uint64_t)j + 1) * 0xD1B54A32D192ED03ULL);
+  uint32_t m = (uint32_t)(x >> 40);
+  return __fsub_rn(__fmul_rn((float)m, 1.0f / 8388608.0f), 1.0f);
+}
+
+__global__ void ph_synth_rows_kernel(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
+                                     uint64_t seed, int normalize) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  float *row = rows + r * (uint64_t)ld;
+  uint64_t key = seed + first + r;
+  float ss = 0.0f;
+  for (uint32_t j = 0; j < dim; j++) {
+    float f = ph_synth_component(key, j);
+    ss = __fadd_rn(ss, __fmul_rn(f, f));  // no contraction: matches the sequential host sum
+  }
+  float norm = normalize ? sqrtf(ss) : 1.0f;
+  for (uint32_t j = 0; j < dim; j++) {
+    float f = ph_synth_component(key, j);
+    row[j] = normalize ? __fdiv_rn(f, norm) : f;
+  }
+  for (uint32_t j = dim; j < ld; j++) row[j] = 0.0f;
+}
+
+int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld, uint64_t seed,
+                  int normalize, hipStream_t s) {
+  if (count == 0) return 0;
+  uint32_t blocks = (uint32_t)((count + 63) / 64);
+  hipLaunchKernelGGL(ph_synth_rows_kernel, dim3(blocks), dim3(64), 0, s, rows_dev, first, count, dim, ld, seed,
+                     normalize);
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void ph_fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+int ph_fill_u32(uint32_t *p, uint32_t v, uint64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(ph_fill_u32_kernel, dim3(blocks), dim3(256), 0, s, p, v, n);
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void ph_scatter_vec2node_kernel(const uint32_t *nodes, uint32_t n, uint32_t *vec2node) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    vec2node[nodes[i]] = i;
+}
+int ph_scatter_vec2node(const uint32_t *nodes, uint32_t n, uint32_t *vec2node, hipStream_t s) {
+  if (n == 0) return 0;
+  uint32_t blocks = std::min<uint32_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(ph_scatter_vec2node_kernel, dim3(blocks), dim3(256), 0, s, nodes, n, vec2node);
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void ph_count_nan_kernel(const float *rows, uint64_t n, uint32_t *out) {
+  uint32_t c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    float f = rows[i];
+    c += (f != f) ? 1u : 0u;
+  }
+  if (c) atomicAdd(out, c);
+}
+int ph_count_nan(const float *rows, uint64_t n_floats, uint32_t *out_count_dev, hipStream_t s) {
+  if (n_floats == 0) return 0;
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((n_floats + 255) / 256, 8192);
+  hipLaunchKernelGGL(ph_count_nan_kernel, dim3(blocks), dim3(256), 0, s, rows, n_floats, out_count_dev);
+  PH_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,155 @@
+// Internal declarations of libphnsw (gfx950 only).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/phnsw.h"
+
+#define PH_EMPTY32 0xFFFFFFFFu
+#define PH_FMAX 3.4028234663852886e38f
+#define PH_MAX_LAYERS 24
+#define PH_WAVE 64
+
+void ph_set_error(const char *fmt, ...);
+int ph_hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define PH_HIP(x)                                                       \
+  do {                                                                  \
+    hipError_t e__ = (x);                                               \
+    if (e__ != hipSuccess) return ph_hip_fail(e__, #x, __FILE__, __LINE__); \
+  } while (0)
+
+// ---- device view of one layer (Layer<C>, src/lib.rs:85-91) ----
+// node ids and vector ids are u32 on the device (n <= 2^31 - 1); the u64 <-> u32
+// conversion and the !0 sentinel mapping happen at the ABI boundary.
+struct PhLayerDev {
+  uint32_t n_nodes;
+  uint32_t W;                 // neighborhood_size
+  const uint32_t *nodes;      // [n_nodes] NodeId -> VectorId, ascending
+  const uint32_t *neighbors;  // [n_nodes * W], trailing PH_EMPTY32
+  const uint32_t *vec2node;   // [store n] VectorId -> NodeId or PH_EMPTY32; nullptr = identity
+};
+
+struct PhLayerHost {
+  uint32_t n_nodes = 0, W = 0;
+  uint32_t *nodes = nullptr;
+  uint32_t *neighbors = nullptr;
+  float *nbr_dist = nullptr;  // [n_nodes * W] distance of each occupant to the row owner (build only)
+  uint32_t *vec2node = nullptr;
+  bool identity = false;
+};
+
+struct phnsw_store {
+  int device = 0;
+  float *rows = nullptr;  // [n][ld] flat, HBM
+  bool owns_rows = true;
+  uint64_t n = 0;
+  uint32_t dim = 0, ld = 0;
+  int metric = 0;
+  int refcount = 1;
+};
+
+struct PhWorkspace {
+  // per resident-wave search state: visited bitmap + overflow (frontier spill) list
+  uint32_t *visited = nullptr;
+  uint64_t visited_words = 0;  // per slot
+  uint2 *ovf = nullptr;
+  uint32_t ovf_cap = 0;  // entries per slot
+  uint32_t n_slots = 0;
+  uint32_t *counter = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+struct phnsw_index {
+  phnsw_store *store = nullptr;
+  std::vector<PhLayerHost> layers;  // top first (src/lib.rs:587)
+  phnsw_build_params bp;
+  std::mutex ws_mutex;
+  PhWorkspace ws;
+  float last_kernel_ms = 0.f;
+};
+
+// ---- kernel argument block for the batched greedy search ----
+struct PhSearchArgs {
+  const float *vecs;
+  uint32_t ld;   // floats per row
+  uint32_t nv4;  // ld / 4
+  int metric;
+  const float *queries;  // [nq][ldq] or nullptr
+  uint32_t ldq;
+  const uint32_t *qids;     // or nullptr
+  const uint32_t *exclude;  // or nullptr
+  uint32_t nq;
+  uint32_t n_layers;
+  PhLayerDev layers[PH_MAX_LAYERS];
+  uint32_t ef, upper, probe_depth;
+  uint32_t *out_ids;
+  float *out_d;
+  uint32_t *out_len;
+  uint32_t *out_stats;  // [nq][2] or nullptr
+  uint32_t *status;     // [nq]
+  uint32_t *visited;
+  uint64_t visited_words;
+  uint2 *ovf;
+  uint32_t ovf_cap;
+  uint32_t *counter;
+  // knn mode (Hnsw::knn lib.rs:905-928): bottom layer only, query = node, seed (node, 0.0)
+  uint32_t knn_mode;
+};
+
+// launchers (search.hip)
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream);
+int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uint32_t ovf_cap);
+void ph_workspace_free(PhWorkspace &ws);
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4);
+
+// misc kernels (misc.hip)
+int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
+                  uint64_t seed, int normalize, hipStream_t s);
+int ph_distance_batch(const phnsw_store *st, const float *q_dev, const uint32_t *ids_dev, uint32_t k,
+                      float *out_dev, hipStream_t s);
+int ph_fill_u32(uint32_t *p, uint32_t v, uint64_t n, hipStream_t s);
+int ph_scatter_vec2node(const uint32_t *nodes, uint32_t n, uint32_t *vec2node, hipStream_t s);
+int ph_count_nan(const float *rows, uint64_t n_floats, uint32_t *out_count_dev, hipStream_t s);
+
+// deterministic generators shared by definition with the oracle (host + device)
+__host__ __device__ inline uint64_t ph_mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return x;
+}
+__host__ __device__ inline uint64_t ph_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((__uint128_t)a * b) >> 64);
+#endif
+}
+__host__ __device__ inline uint64_t ph_feistel_perm(uint64_t i, uint64_t domain, uint64_t key) {
+  if (domain <= 1) return 0;
+  uint32_t bits = 0;
+  while (((uint64_t)1 << bits) < domain) bits++;
+  uint32_t h = (bits + 1) / 2;
+  if (h == 0) h = 1;
+  uint64_t mask = ((uint64_t)1 << h) - 1;
+  uint64_t x = i;
+  do {
+    uint64_t L = x >> h, R = x & mask;
+    for (uint32_t r = 0; r < 4; r++) {
+      uint64_t f = ph_mix64(R + key * 0x9E3779B97F4A7C15ULL + r * 0xC2B2AE3D27D4EB4FULL) & mask;
+      uint64_t nl = R;
+      R = L ^ f;
+      L = nl;
+    }
+    x = (L << h) | R;
+  } while (x >= domain);
+  return x;
+}
+void ph_shuffle_u64(uint64_t *v, uint64_t n, uint64_t seed);

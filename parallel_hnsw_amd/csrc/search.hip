@@ -1,0 +1,565 @@
+// K2: batched greedy HNSW search for gfx950 -- one 64-lane wavefront per query.
+//
+// Replaces, for a whole batch of queries at once,
+//   search_layers_instrumented   /root/reference/src/search.rs:93-140
+//   Layer::closest_vectors       /root/reference/src/lib.rs:250-277
+//   Layer::closest_nodes         /root/reference/src/lib.rs:175-248   (the hot loop)
+//   PriorityQueue::merge         /root/reference/src/priority_queue.rs:109-144
+//   Comparator::compare_vec      /root/reference/src/lib.rs:69-73 (+ bigvec.rs:47-53)
+//
+// Mapping to the hardware (DESIGN.md has the long form):
+//  * a wave owns a query for its whole descent; waves pull queries from one atomic counter
+//    (persistent grid, no tail of idle CUs);
+//  * the query vector lives in registers (NV float4 per lane); a candidate row is read as
+//    NV fully coalesced 1 KiB wave-loads (global_load_dwordx4), 4 rows in flight per wave,
+//    fma-accumulated per lane and reduced with an xor butterfly -- this fixed order is the
+//    oracle's ORC_SUM_BLOCKED64, so results are bit-comparable;
+//  * the result queue (PriorityQueue, cap = number_of_candidates) is a sorted (d,id) array
+//    in LDS; a hop's <=64 new candidates are ranked against each other with v_readlane and
+//    against the queue by binary search, then everything moves to its final slot in one
+//    parallel pass (no per-element shifting);
+//  * the reference's unbounded `visit_queue` (every evaluated node, re-sorted each hop,
+//    pop = smallest (d,id)) is represented exactly as: an "expanded" bit on queue entries
+//    + an append-only spill list in HBM for entries that fell out of / never entered the
+//    queue.  All spilled entries are worse than every queue entry, so pop = first
+//    unexpanded queue entry, else the minimum unexpanded spill entry (rare, linear scan);
+//  * `visited` (HashSet) is a per-wave bitmap in HBM driven by returning atomicOr
+//    (test-and-set in one L2 round trip), cleared after each layer by walking queue+spill.
+//
+// Hand-written for CDNA4: wave64 ballots/readlane, LDS queue, no portability layer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "phnsw_internal.h"
+
+#include "phnsw_device.h"
+
+template <int CAPC, int NV>
+__global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
+  extern __shared__ uint32_t smem[];
+  constexpr int CAP = CAPC * 64;
+  uint32_t *Cid = smem;                    // running candidates: VectorIds (search.rs:110)
+  float *Cd = (float *)(smem + CAP);       //
+  uint32_t *Qid = smem + 2 * CAP;          // layer queue: NodeIds | EXPF (lib.rs:264)
+  float *Qd = (float *)(smem + 3 * CAP);   //
+  uint32_t *S = smem + 4 * CAP;            // prefix scratch [CAP + 64]
+
+  const uint32_t lane = threadIdx.x;
+  const uint64_t lt = lanemask_lt(lane);
+  uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
+  uint2 *ovf = a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
+  const uint32_t ef = a.ef;
+  const uint32_t nv4 = a.nv4;
+  const bool l2 = a.metric == PHNSW_METRIC_L2;
+
+  for (;;) {
+    uint32_t q = 0;
+    if (lane == 0) q = atomicAdd(a.counter, 1u);
+    q = rfl32(q);
+    if (q >= a.nq) break;
+
+    const uint32_t last_layer = a.n_layers - 1;
+    uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[q] : (a.qids ? a.qids[q] : 0u);
+    const float4 *qrow = (a.queries && !a.knn_mode)
+                             ? (const float4 *)(a.queries + (uint64_t)q * a.ldq)
+                             : (const float4 *)(a.vecs + (uint64_t)qvec * a.ld);
+    float4 qv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      qv[k] = (c < nv4) ? qrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
+    uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
+    uint32_t clen = 0;
+
+    if (!a.knn_mode) {
+      // entry_vector + distance_from_entry  search.rs:101-111
+      uint32_t entry = a.layers[0].nodes[0];
+      float r = wave_sum(row_partial<NV>((const float4 *)(a.vecs + (uint64_t)entry * a.ld), qv, nv4, lane, l2));
+      float d0 = finalize_metric(r, a.metric);
+      n_dist = 1;
+      if (lane == 0) {
+        Cid[0] = entry;
+        Cd[0] = d0;
+      }
+      clen = 1;
+    }
+    __syncthreads();
+
+    for (uint32_t li = a.knn_mode ? last_layer : 0; li < a.n_layers && err == ST_OK; li++) {
+      const PhLayerDev L = a.layers[li];
+      const bool identity = L.vec2node == nullptr;
+      // ---- closest_vectors: VectorId -> NodeId, queue = new(cap); merge_pairs  lib.rs:258-266
+      uint32_t qlen;
+      if (a.knn_mode) {
+        // pq.merge_pairs(&[(node, 0.0)])  lib.rs:917-918
+        if (lane == 0) {
+          Qid[0] = q;
+          Qd[0] = 0.0f;
+          atomicOr(&vis[q >> 5], 1u << (q & 31));
+        }
+        qlen = 1;
+      } else {
+        bool miss = false;
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          if (i < clen) {
+            uint32_t vid = Cid[i];
+            uint32_t nid = identity ? vid : L.vec2node[vid];
+            if (nid >= L.n_nodes) {  // get_node(v).unwrap() would panic  lib.rs:261
+              miss = true;
+              nid = 0;
+            }
+            Qid[i] = nid;
+            Qd[i] = Cd[i];
+          }
+        }
+        if (__ballot(miss)) {
+          err = ST_MISSING;
+          break;
+        }
+        // visited = candidates ids  lib.rs:187
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          if (i < clen) {
+            uint32_t nid = Qid[i];
+            atomicOr(&vis[nid >> 5], 1u << (nid & 31));
+          }
+        }
+        qlen = clen;
+      }
+      __syncthreads();
+
+      // ---- closest_nodes  lib.rs:175-248
+      uint32_t ovf_n = 0;
+      uint32_t pd = a.probe_depth;
+      for (;;) {
+        // visit_queue.pop(): smallest (d,id) among not yet expanded nodes  lib.rs:191,243-244
+        int pop = -1;
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          if (pop < 0) {
+            uint32_t i = lane + 64u * c;
+            bool f = i < qlen && !(Qid[i] & EXPF);
+            uint64_t b = __ballot(f);
+            if (b) pop = 64 * c + __builtin_ctzll(b);
+          }
+        }
+        uint32_t cur;
+        if (pop >= 0) {
+          cur = Qid[pop];
+          if (lane == 0) Qid[pop] = cur | EXPF;
+        } else {
+          if (ovf_n == 0) break;
+          wait_vm0();  // spill stores of this wave have reached L2
+          uint64_t best = KEY_NONE;
+          uint32_t bi = 0;
+          for (uint32_t i = lane; i < ovf_n; i += 64) {
+            uint32_t id = __hip_atomic_load(&ovf[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(id & EXPF)) {
+              uint32_t db = __hip_atomic_load(&ovf[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              uint64_t k = mkkey(__uint_as_float(db), id);
+              if (k < best) {
+                best = k;
+                bi = i;
+              }
+            }
+          }
+#pragma unroll
+          for (int s = 32; s >= 1; s >>= 1) {
+            uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(best >> 32), s) << 32) | __shfl_xor((uint32_t)best, s);
+            uint32_t oi = __shfl_xor(bi, s);
+            if (o < best) {
+              best = o;
+              bi = oi;
+            }
+          }
+          if (best == KEY_NONE) break;  // frontier exhausted
+          cur = (uint32_t)best & IDM;
+          if (lane == 0)
+            __hip_atomic_store(&ovf[bi].x, cur | EXPF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cur &= IDM;
+        n_hops++;
+
+        // get_neighbors(next) + filter(!visited)  lib.rs:195-198
+        uint32_t nb = PH_EMPTY32;
+        if (lane < L.W) nb = L.neighbors[(uint64_t)cur * L.W + lane];
+        bool fresh = false;
+        if (nb < L.n_nodes) {
+          uint32_t bit = 1u << (nb & 31);
+          uint32_t old = atomicOr(&vis[nb >> 5], bit);
+          fresh = !(old & bit);
+        }
+        const uint64_t fm = __ballot(fresh);
+        const uint32_t m = __popcll(fm);
+        n_dist += m;
+        uint32_t vid = 0;
+        if (fresh) vid = identity ? nb : L.nodes[nb];
+
+        // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202
+        float myd = 0.f;
+        {
+          uint64_t rem = fm;
+          while (rem) {
+            int l0 = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            int l1 = rem ? __builtin_ctzll(rem) : l0;
+            rem &= rem ? rem - 1 : 0;
+            int l2_ = rem ? __builtin_ctzll(rem) : l0;
+            rem &= rem ? rem - 1 : 0;
+            int l3 = rem ? __builtin_ctzll(rem) : l0;
+            rem &= rem ? rem - 1 : 0;
+            const float4 *r0 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l0) * a.ld);
+            const float4 *r1 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l1) * a.ld);
+            const float4 *r2 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l2_) * a.ld);
+            const float4 *r3 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l3) * a.ld);
+            float p0 = row_partial<NV>(r0, qv, nv4, lane, l2);
+            float p1 = row_partial<NV>(r1, qv, nv4, lane, l2);
+            float p2 = row_partial<NV>(r2, qv, nv4, lane, l2);
+            float p3 = row_partial<NV>(r3, qv, nv4, lane, l2);
+            p0 = wave_sum(p0);
+            p1 = wave_sum(p1);
+            p2 = wave_sum(p2);
+            p3 = wave_sum(p3);
+            if ((int)lane == l0) myd = finalize_metric(p0, a.metric);
+            if ((int)lane == l1) myd = finalize_metric(p1, a.metric);
+            if ((int)lane == l2_) myd = finalize_metric(p2, a.metric);
+            if ((int)lane == l3) myd = finalize_metric(p3, a.metric);
+          }
+        }
+
+        // candidates.merge_pairs(sorted batch)  lib.rs:206,226 / priority_queue.rs:109-144,
+        // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
+        // (visited), so final slot = (#queue keys below) + (#batch keys below).
+        const uint64_t key = fresh ? mkkey(myd, nb) : KEY_NONE;
+        uint32_t qi[CAPC];
+        float qd[CAPC];
+        uint64_t qk[CAPC];
+        uint32_t sh[CAPC];
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          sh[c] = 0;
+          if (i < qlen) {
+            qi[c] = Qid[i];
+            qd[c] = Qd[i];
+            qk[c] = mkkey(qd[c], qi[c]);
+          } else {
+            qi[c] = PH_EMPTY32;
+            qd[c] = PH_FMAX;
+            qk[c] = KEY_NONE;
+          }
+        }
+        uint32_t rank = 0;
+        {
+          uint64_t rem = fm;
+          while (rem) {
+            int j = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            uint64_t kj = rl64(key, j);
+            rank += (kj < key) ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < CAPC; c++) sh[c] += (kj < qk[c]) ? 1u : 0u;
+          }
+        }
+        uint32_t pos = 0;
+        if (fresh) pos = lds_lower_bound(Qid, Qd, qlen, key);
+        const uint32_t newpos = pos + rank;
+
+        // merge()'s return value (priority_queue.rs:109-144), closed form for a sorted,
+        // duplicate-free batch e_0 < e_1 < ...: the first element decides.  It is inserted
+        // (true) unless it ranks past a full queue; then Err(i>=cap) => break => false,
+        // except when its priority ties the queue's tail (Ok branch returns cap, false) and
+        // a second element follows (Err(0) on the empty slice => true without writing).
+        bool did = false;
+        if (m > 0) {
+          uint64_t e0 = __ballot(fresh && rank == 0);
+          int le = __builtin_ctzll(e0);
+          uint32_t pos0 = rl32(pos, le);
+          float d0 = __uint_as_float(rl32(__float_as_uint(myd), le));
+          did = pos0 < ef || (qlen == ef && Qd[ef - 1] == d0 && m >= 2);
+        }
+        __syncthreads();  // every lane has its queue slice in registers
+
+        // move everything to its final slot; what falls past `ef` is spilled
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          bool has = i < qlen;
+          uint32_t np = i + sh[c];
+          if (has && np < ef) {
+            Qid[np] = qi[c];
+            Qd[np] = qd[c];
+          }
+          bool spill = has && np >= ef;
+          uint64_t sm = __ballot(spill);
+          if (sm) {
+            uint32_t at = ovf_n + __popcll(sm & lt);
+            if (spill && at < a.ovf_cap) ovf[at] = make_uint2(qi[c], __float_as_uint(qd[c]));
+            ovf_n += __popcll(sm);
+          }
+        }
+        {
+          if (fresh && newpos < ef) {
+            Qid[newpos] = nb;
+            Qd[newpos] = myd;
+          }
+          bool spill = fresh && newpos >= ef;
+          uint64_t sm = __ballot(spill);
+          if (sm) {
+            uint32_t at = ovf_n + __popcll(sm & lt);
+            if (spill && at < a.ovf_cap) ovf[at] = make_uint2(nb, __float_as_uint(myd));
+            ovf_n += __popcll(sm);
+          }
+        }
+        qlen = min(ef, qlen + m);
+        __syncthreads();
+        if (ovf_n > a.ovf_cap) {
+          err = ST_OVERFLOW;
+          break;
+        }
+        if (!did) {  // lib.rs:233-238
+          pd -= 1;
+          if (pd == 0) break;
+        }
+      }
+      if (err != ST_OK) break;
+
+      // ---- clear this layer's visited bits (queue + spill hold every evaluated node)
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t i = lane + 64u * c;
+        if (i < qlen) vis[(Qid[i] & IDM) >> 5] = 0u;
+      }
+      if (ovf_n) {
+        wait_vm0();
+        for (uint32_t i = lane; i < ovf_n; i += 64) {
+          uint32_t id = __hip_atomic_load(&ovf[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IDM;
+          vis[id >> 5] = 0u;
+        }
+      }
+      wait_vm0();
+
+      // ---- closest_vectors tail: NodeId -> VectorId, filter(include), take(count)  lib.rs:268-276
+      const uint32_t candidate_count = (a.n_layers == 1 || li == last_layer) ? ef : a.upper;  // search.rs:122-126
+      uint32_t bv[CAPC];
+      float bd[CAPC];
+      uint32_t bpos[CAPC];
+      uint32_t kept = 0;
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t i = lane + 64u * c;
+        bool has = i < qlen;
+        uint32_t nid = has ? (Qid[i] & IDM) : 0u;
+        bd[c] = has ? Qd[i] : PH_FMAX;
+        bv[c] = has ? (identity ? nid : L.nodes[nid]) : PH_EMPTY32;
+        bool keep = has && bv[c] != excl;
+        uint64_t km = __ballot(keep);
+        uint32_t at = kept + __popcll(km & lt);
+        bpos[c] = (keep && at < candidate_count) ? at : PH_EMPTY32;
+        kept += __popcll(km);
+      }
+      const uint32_t blen = min(kept, candidate_count);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        if (bpos[c] != PH_EMPTY32) {
+          Qid[bpos[c]] = bv[c];
+          Qd[bpos[c]] = bd[c];
+        }
+      }
+      __syncthreads();
+
+      // ---- candidates.merge_pairs(&closest)  search.rs:136 : sorted set union, cap ef.
+      // An element present in both lists (same id => same distance) is kept once.
+      uint32_t ci[CAPC];
+      float cd[CAPC];
+      uint32_t cpos[CAPC];
+      uint32_t dups = 0;
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t i = lane + 64u * c;
+        bool has = i < clen;
+        ci[c] = has ? Cid[i] : PH_EMPTY32;
+        cd[c] = has ? Cd[i] : PH_FMAX;
+        bool dup = false;
+        uint32_t lb = 0;
+        if (has) {
+          uint64_t k = mkkey(cd[c], ci[c]);
+          lb = lds_lower_bound(Qid, Qd, blen, k);
+          dup = lb < blen && mkkey(Qd[lb], Qid[lb]) == k;
+        }
+        uint64_t dm = __ballot(dup);
+        uint32_t pre = dups + __popcll(dm & lt);  // duplicates among C[0..i)
+        S[i] = pre;
+        cpos[c] = (has && !dup) ? (i - pre) + lb : PH_EMPTY32;
+        dups += __popcll(dm);
+      }
+      if (lane == 0) S[CAP] = dups;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t j = lane + 64u * c;
+        bool has = j < blen;
+        bv[c] = has ? Qid[j] : PH_EMPTY32;
+        bd[c] = has ? Qd[j] : PH_FMAX;
+        bpos[c] = PH_EMPTY32;
+        if (has) {
+          uint32_t la = lds_lower_bound(Cid, Cd, clen, mkkey(bd[c], bv[c]));
+          uint32_t dupb = la < clen ? S[la] : S[CAP];  // S[clen] when la == clen
+          if (la == clen) dupb = dups;
+          bpos[c] = j + (la - dupb);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        if (cpos[c] < ef) {
+          Cid[cpos[c]] = ci[c];
+          Cd[cpos[c]] = cd[c];
+        }
+        if (bpos[c] < ef) {
+          Cid[bpos[c]] = bv[c];
+          Cd[bpos[c]] = bd[c];
+        }
+      }
+      clen = min(ef, clen - dups + blen);
+      __syncthreads();
+    }
+
+    if (err != ST_OK) {
+      // leave the slot clean for the next query: wipe the whole bitmap (rare path)
+      for (uint64_t w = lane; w < a.visited_words; w += 64) vis[w] = 0u;
+      wait_vm0();
+      clen = 0;
+    }
+    // (candidates.iter().collect(), ..)  search.rs:139
+    for (uint32_t i = lane; i < ef; i += 64) {
+      a.out_ids[(uint64_t)q * ef + i] = i < clen ? Cid[i] : PH_EMPTY32;
+      a.out_d[(uint64_t)q * ef + i] = i < clen ? Cd[i] : PH_FMAX;
+    }
+    if (lane == 0) {
+      a.out_len[q] = clen;
+      a.status[q] = err;
+      if (a.out_stats) {
+        a.out_stats[2 * (uint64_t)q] = n_dist;
+        a.out_stats[2 * (uint64_t)q + 1] = n_hops;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ host side
+
+typedef void (*ph_search_fn)(PhSearchArgs);
+
+static int pick_capc(uint32_t ef) { return ef <= 128 ? 2 : (ef <= 512 ? 8 : (ef <= 1024 ? 16 : 0)); }
+static int pick_nv(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
+
+static ph_search_fn pick_kernel(int capc, int nv) {
+#define PH_K(C, N) \
+  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, N>;
+  PH_K(2, 1) PH_K(2, 3) PH_K(2, 6)
+  PH_K(8, 1) PH_K(8, 3) PH_K(8, 6)
+  PH_K(16, 1) PH_K(16, 3) PH_K(16, 6)
+#undef PH_K
+  return nullptr;
+}
+
+static size_t lds_bytes(int capc) { return (size_t)(5 * capc * 64 + 64) * 4; }
+
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4) {
+  int capc = pick_capc(ef), nv = pick_nv(nv4);
+  ph_search_fn fn = pick_kernel(capc, nv);
+  if (!fn) return 0;
+  int dev = 0;
+  hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds_bytes(capc)) != hipSuccess ||
+      per_cu <= 0)
+    per_cu = 8;
+  int cap = 16;
+  if (const char *e = getenv("PHNSW_WAVES_PER_CU")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  per_cu = std::min(per_cu, cap);
+  return (uint32_t)(per_cu * prop.multiProcessorCount);
+}
+
+void ph_workspace_free(PhWorkspace &ws) {
+  if (ws.visited) hipFree(ws.visited);
+  if (ws.ovf) hipFree(ws.ovf);
+  if (ws.counter) hipFree(ws.counter);
+  if (ws.ev0) hipEventDestroy(ws.ev0);
+  if (ws.ev1) hipEventDestroy(ws.ev1);
+  ws = PhWorkspace();
+}
+
+int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uint32_t ovf_cap) {
+  uint64_t max_nodes = 0;
+  for (auto &l : ix->layers) max_nodes = std::max<uint64_t>(max_nodes, l.n_nodes);
+  uint64_t words = (max_nodes + 31) / 32 + 1;
+  uint32_t slots = ph_search_slots(ef, ix->store->ld / 4);
+  if (slots == 0) {
+    ph_set_error("unsupported search shape: ef=%u dim=%u (ef <= 1024, dim <= 1536)", ef, ix->store->dim);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  if (!ws.counter) {
+    PH_HIP(hipMalloc(&ws.counter, 256));
+    PH_HIP(hipEventCreate(&ws.ev0));
+    PH_HIP(hipEventCreate(&ws.ev1));
+  }
+  if (ws.n_slots < slots || ws.visited_words < words) {
+    if (ws.visited) PH_HIP(hipFree(ws.visited));
+    ws.visited = nullptr;
+    uint32_t ns = std::max(ws.n_slots, slots);
+    uint64_t nw = std::max(ws.visited_words, words);
+    PH_HIP(hipMalloc(&ws.visited, (size_t)ns * nw * 4));
+    PH_HIP(hipMemset(ws.visited, 0, (size_t)ns * nw * 4));
+    if (ws.ovf && ws.n_slots < ns) {
+      PH_HIP(hipFree(ws.ovf));
+      ws.ovf = nullptr;
+    }
+    ws.n_slots = ns;
+    ws.visited_words = nw;
+  }
+  if (!ws.ovf || ws.ovf_cap < ovf_cap) {
+    if (ws.ovf) PH_HIP(hipFree(ws.ovf));
+    ws.ovf = nullptr;
+    ws.ovf_cap = std::max(ws.ovf_cap, ovf_cap);
+    PH_HIP(hipMalloc(&ws.ovf, (size_t)ws.n_slots * ws.ovf_cap * sizeof(uint2)));
+  }
+  return 0;
+}
+
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream) {
+  int capc = pick_capc(a.ef), nv = pick_nv(a.nv4);
+  ph_search_fn fn = pick_kernel(capc, nv);
+  if (!fn) {
+    ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.nv4);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  a.visited = ws.visited;
+  a.visited_words = ws.visited_words;
+  a.ovf = ws.ovf;
+  a.ovf_cap = ws.ovf_cap;
+  a.counter = ws.counter;
+  uint32_t slots = std::min<uint32_t>(ph_search_slots(a.ef, a.nv4), ws.n_slots);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
+  if (grid == 0) return 0;
+  PH_HIP(hipMemsetAsync(ws.counter, 0, 4, stream));
+  PH_HIP(hipEventRecord(ws.ev0, stream));
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc), stream, a);
+  PH_HIP(hipGetLastError());
+  PH_HIP(hipEventRecord(ws.ev1, stream));
+  ws.timed = true;
+  return 0;
+}

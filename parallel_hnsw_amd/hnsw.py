@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference crate's public surface for the hot path
+(terminusdb-labs/parallel-hnsw src/lib.rs:585-1686, src/parameters.rs, src/types.rs),
+implemented over the C ABI of libphnsw.  Names, argument meaning and result ordering
+follow the reference so tests read like its own tests:
+
+    Hnsw.generate(c, vs, bp)            lib.rs:825-830
+    hnsw.search(AbstractVector, sp)     lib.rs:663-665   -> [(VectorId, f32)] sorted (d, id)
+    hnsw.improve_index(bp)              lib.rs:1664-1669
+    hnsw.knn(k, probe_depth)            lib.rs:905-928
+    hnsw.layers[i].nodes / .neighbors   lib.rs:85-91  (top first)
+
+`VectorStore` plays the role of the Comparator (store + metric, bigvec.rs:38-57); the
+per-pair compare_raw seam is replaced by batches (distance_batch / search_batch).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BuildParams, OptimizationParams, PhnswError, SearchParams, check, lib
+
+EMPTY = 0xFFFFFFFFFFFFFFFF  # VectorId::MAX / NodeId::MAX (types.rs:8-13)
+METRIC_COSINE_HALF, METRIC_ONE_MINUS_DOT, METRIC_L2 = 0, 1, 2
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def SearchParameters(number_of_candidates=300, upper_layer_candidate_count=300, probe_depth=2):
+    return SearchParams(number_of_candidates, upper_layer_candidate_count, probe_depth)
+
+
+def BuildParameters(**kw):
+    bp = BuildParams()
+    lib().phnsw_default_build_params(C.byref(bp))
+    for k, v in kw.items():
+        if not hasattr(bp, k):
+            raise TypeError("unknown build parameter %r" % k)
+        setattr(bp, k, v)
+    return bp
+
+
+class Stored:
+    """AbstractVector::Stored(VectorId)  types.rs:40-43"""
+
+    def __init__(self, vector_id):
+        self.id = int(vector_id)
+
+
+class Unstored:
+    """AbstractVector::Unstored(&T)"""
+
+    def __init__(self, vec):
+        self.vec = np.ascontiguousarray(vec, dtype=np.float32)
+
+
+class VectorStore:
+    """flat HBM vector store + metric: the Comparator of the GPU path"""
+
+    def __init__(self, rows=None, metric=METRIC_COSINE_HALF, device=0, _handle=None):
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            assert rows.ndim == 2
+            check(lib().phnsw_store_create(_p(rows), rows.shape[0], rows.shape[1], metric, device, C.byref(self._h)))
+        n, dim, ld, m = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_int()
+        ptr = C.c_void_p()
+        check(lib().phnsw_store_info(self._h, C.byref(n), C.byref(dim), C.byref(ld), C.byref(m), C.byref(ptr)))
+        self.n, self.dim, self.ld, self.metric, self.rows_dev = n.value, dim.value, ld.value, m.value, ptr.value
+        self.device = device
+
+    @classmethod
+    def synthetic(cls, n, dim, seed=42, first=0, normalize=True, metric=METRIC_COSINE_HALF, device=0):
+        """make_random_hnsw's data (bigvec.rs:23-29, 59-65) generated on the GPU"""
+        h = C.c_void_p()
+        check(lib().phnsw_store_create_synthetic(first, n, dim, seed, int(normalize), metric, device, C.byref(h)))
+        return cls(_handle=h, device=device)
+
+    @classmethod
+    def from_device(cls, data_ptr, n, dim, ld, metric=METRIC_COSINE_HALF, device=0, keepalive=None):
+        h = C.c_void_p()
+        check(lib().phnsw_store_create_device(C.c_void_p(data_ptr), n, dim, ld, metric, device, C.byref(h)))
+        s = cls(_handle=h, device=device)
+        s._keepalive = keepalive
+        return s
+
+    def read(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((count, self.dim), dtype=np.float32)
+        check(lib().phnsw_store_read(self._h, first, count, _p(out)))
+        return out
+
+    def compare_vec(self, v, ids):
+        """Comparator::compare_vec batched (lib.rs:69-73): distances from v to Stored(ids)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = np.empty(len(ids), dtype=np.float32)
+        if isinstance(v, Stored):
+            check(lib().phnsw_distance_batch(self._h, None, v.id, _p(ids), len(ids), _p(out)))
+        else:
+            q = v.vec if isinstance(v, Unstored) else np.ascontiguousarray(v, dtype=np.float32)
+            assert q.shape[-1] == self.dim
+            check(lib().phnsw_distance_batch(self._h, _p(q), 0, _p(ids), len(ids), _p(out)))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().phnsw_store_destroy(h)
+
+
+class Layer:
+    """Layer { neighborhood_size, nodes, neighbors }  lib.rs:85-91 (host copies, u64)"""
+
+    def __init__(self, nodes, neighbors, neighborhood_size):
+        self.nodes = nodes
+        self.neighbors = neighbors
+        self.neighborhood_size = neighborhood_size
+
+    def node_count(self):
+        return len(self.nodes)
+
+    def get_neighbors(self, n):
+        row = self.neighbors[n]
+        return row[row != EMPTY]  # trailing sentinels trimmed (lib.rs:114-125)
+
+
+class Hnsw:
+    def __init__(self, store, handle, build_parameters=None):
+        self.store = store
+        self._h = handle
+        self.build_parameters = build_parameters or BuildParameters()
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def generate(cls, c, vs, bp=None, progress=None):
+        """Hnsw::generate(c, vs, bp, progress)  lib.rs:825-893"""
+        bp = bp or BuildParameters()
+        vs = np.ascontiguousarray(vs, dtype=np.uint64)
+        h = C.c_void_p()
+        cb = _lib.PROGRESS_CB(progress) if progress else None
+        check(lib().phnsw_build(c._h, _p(vs), len(vs), C.byref(bp), cb, None, C.byref(h)))
+        return cls(c, h, bp)
+
+    @classmethod
+    def from_layers(cls, c, layers, bp=None):
+        """adopt [(nodes, neighbors[n, W])...] top first, e.g. deserialised from the Rust crate"""
+        L = len(layers)
+        nodes = [np.ascontiguousarray(l[0], dtype=np.uint64) for l in layers]
+        nbs = [np.ascontiguousarray(l[1], dtype=np.uint64).reshape(len(nodes[i]), -1) for i, l in enumerate(layers)]
+        counts = np.array([len(x) for x in nodes], dtype=np.uint64)
+        widths = np.array([nb.shape[1] for nb in nbs], dtype=np.uint64)
+        pn = (C.c_void_p * L)(*[x.ctypes.data for x in nodes])
+        pb = (C.c_void_p * L)(*[x.ctypes.data for x in nbs])
+        h = C.c_void_p()
+        check(lib().phnsw_index_from_layers(c._h, L, _p(counts), _p(widths), pn, pb, C.byref(h)))
+        return cls(c, h, bp)
+
+    def generate_layer(self, vs, neighborhood_size, bp=None):
+        vs = np.ascontiguousarray(vs, dtype=np.uint64)
+        check(lib().phnsw_generate_layer(self._h, _p(vs), len(vs), neighborhood_size,
+                                         C.byref(bp or self.build_parameters)))
+
+    def link_layer_to_better_neighbors(self, layer_from_top, sp):
+        """lib.rs:1070-1082; returns the number of new edges"""
+        added = C.c_uint64()
+        check(lib().phnsw_link_layer(self._h, layer_from_top, C.byref(sp), self.build_parameters.neighborhood_size,
+                                     C.byref(added)))
+        return added.value
+
+    def improve_index(self, bp=None, progress=None):
+        out = C.c_float()
+        cb = _lib.PROGRESS_CB(progress) if progress else None
+        check(lib().phnsw_improve_index(self._h, C.byref(bp or self.build_parameters), cb, None, C.byref(out)))
+        return out.value
+
+    def improve_neighbors_upto(self, upto, bp=None, last_recall=None):
+        out = C.c_float()
+        check(lib().phnsw_improve_neighbors_upto(self._h, upto, C.byref(bp or self.build_parameters),
+                                                 float("nan") if last_recall is None else last_recall,
+                                                 C.byref(out)))
+        return out.value
+
+    def stochastic_recall_at(self, at, op=None):
+        out = C.c_float()
+        op = op or self.build_parameters.optimization
+        check(lib().phnsw_stochastic_recall_at(self._h, at, C.byref(op), C.byref(out)))
+        return out.value
+
+    def stochastic_recall(self, op=None):
+        return self.stochastic_recall_at(self.layer_count() - 1, op)
+
+    # -- accessors ----------------------------------------------------------
+    def layer_count(self):
+        return lib().phnsw_index_layer_count(self._h)
+
+    def _layer(self, lft):
+        n, w = C.c_uint64(), C.c_uint64()
+        check(lib().phnsw_index_layer_info(self._h, lft, C.byref(n), C.byref(w)))
+        nodes = np.empty(n.value, dtype=np.uint64)
+        nb = np.empty((n.value, w.value), dtype=np.uint64)
+        check(lib().phnsw_index_layer_read(self._h, lft, _p(nodes), _p(nb)))
+        return Layer(nodes, nb, w.value)
+
+    @property
+    def layers(self):
+        """Vec<Layer>, top first (lib.rs:587)"""
+        return [self._layer(i) for i in range(self.layer_count())]
+
+    def get_layer(self, i):
+        """counts from the bottom (lib.rs:604-606)"""
+        return self._layer(self.layer_count() - i - 1)
+
+    def entry_vector(self):
+        return int(self._layer(0).nodes[0])
+
+    def vector_count(self):
+        n = C.c_uint64()
+        check(lib().phnsw_index_layer_info(self._h, self.layer_count() - 1, C.byref(n), None))
+        return n.value
+
+    # -- search -------------------------------------------------------------
+    def search_batch(self, queries=None, qids=None, sp=None, exclude=None, upto=0, stats=False):
+        """Hnsw::search for many queries; returns (ids[nq, ef] u64, d[nq, ef] f32, len[nq])"""
+        sp = sp or SearchParameters()
+        ef = sp.number_of_candidates
+        if queries is not None:
+            q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+            assert q.shape[1] == self.store.dim
+            nq = q.shape[0]
+        else:
+            qi = np.ascontiguousarray(qids, dtype=np.uint64)
+            nq = len(qi)
+        ids = np.empty((nq, ef), dtype=np.uint64)
+        d = np.empty((nq, ef), dtype=np.float32)
+        ln = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros((nq, 2), dtype=np.uint64) if stats else None
+        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint64)
+        if queries is not None:
+            check(lib().phnsw_search_batch(self._h, _p(q), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d), _p(ln), _p(st)))
+        else:
+            check(lib().phnsw_search_batch_stored(self._h, _p(qi), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d),
+                                                  _p(ln), _p(st)))
+        return (ids, d, ln, st) if stats else (ids, d, ln)
+
+    def search(self, v, sp=None):
+        """Hnsw::search(v, sp) -> Vec<(VectorId, f32)>  lib.rs:663-665"""
+        if isinstance(v, Stored):
+            ids, d, ln = self.search_batch(qids=[v.id], sp=sp)
+        else:
+            ids, d, ln = self.search_batch(queries=v.vec if isinstance(v, Unstored) else v, sp=sp)
+        return [(int(ids[0, i]), d[0, i]) for i in range(int(ln[0]))]
+
+    def search_upto(self, v, sp, upto_layer_from_top):
+        """lib.rs:654-661"""
+        if isinstance(v, Stored):
+            ids, d, ln = self.search_batch(qids=[v.id], sp=sp, upto=upto_layer_from_top)
+        else:
+            ids, d, ln = self.search_batch(queries=v.vec, sp=sp, upto=upto_layer_from_top)
+        return [(int(ids[0, i]), d[0, i]) for i in range(int(ln[0]))]
+
+    def knn(self, k, probe_depth):
+        """Hnsw::knn  lib.rs:905-928 -> [(VectorId, [(VectorId, f32)])]"""
+        n = self.vector_count()
+        ids = np.empty((n, k), dtype=np.uint64)
+        d = np.empty((n, k), dtype=np.float32)
+        ln = np.zeros(n, dtype=np.uint64)
+        check(lib().phnsw_knn(self._h, k, probe_depth, _p(ids), _p(d), _p(ln)))
+        nodes = self._layer(self.layer_count() - 1).nodes
+        return [(int(nodes[i]), [(int(ids[i, j]), d[i, j]) for j in range(int(ln[i]))]) for i in range(n)]
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        check(lib().phnsw_last_search_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().phnsw_index_destroy(h)
