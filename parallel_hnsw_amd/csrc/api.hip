@@ -474,7 +474,8 @@ static uint32_t default_ovf_cap(uint32_t ef) { return std::max<uint32_t>(8192u, 
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
-                     uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream) {
+                     uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
+                     uint32_t *out_hit) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -489,6 +490,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.out_stats = out_stats;
   a.status = status;
   a.knn_mode = knn_mode;
+  a.out_stride = out_stride;
+  a.out_hit = out_hit;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
   int rc = ph_workspace_ensure(ix, mix->ws, a.ef, ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;

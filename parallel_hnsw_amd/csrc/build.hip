@@ -1,9 +1,1051 @@
-#include "phnsw_internal.h"
-// placeholder until the GPU build lands (next commit)
-#define STUB(name, ...) extern "C" int name(__VA_ARGS__) { ph_set_error(#name ": not implemented yet"); return PHNSW_E_UNSUPPORTED; }
-STUB(phnsw_build, phnsw_store *, const uint64_t *, uint64_t, const phnsw_build_params *, phnsw_progress_cb, void *, phnsw_index **)
-STUB(phnsw_generate_layer, phnsw_index *, const uint64_t *, uint64_t, uint64_t, const phnsw_build_params *)
-STUB(phnsw_link_layer, phnsw_index *, uint32_t, const phnsw_search_params *, uint64_t, uint64_t *)
-STUB(phnsw_improve_index, phnsw_index *, const phnsw_build_params *, phnsw_progress_cb, void *, float *)
-STUB(phnsw_improve_neighbors_upto, phnsw_index *, uint32_t, const phnsw_build_params *, float, float *)
-STUB(phnsw_stochastic_recall_at, phnsw_index *, uint32_t, const phnsw_optimization_params *, float *)
+// Index construction on gfx950: Hnsw::generate / generate_layer / link rounds / recall
+// (/root/reference/src/lib.rs:675-893, 1070-1154, 1463-1544, 1546-1686; promotion
+// lib.rs:1273-1427 is not performed -- SURVEY section 8 row f2).
+//
+// Every expensive step of the reference build is "run search_layers for every node of a
+// layer" (K2, search.hip) or "a distance batch per node" (K3 below); what remains is
+// integer bookkeeping.  The reference mutates neighbour rows under per-row RwLocks in
+// thread-schedule order (lib.rs:789-815, 1102-1147); here each round is evaluated against
+// a snapshot and resolved per target row as
+//        row' = best-W by (distance, id) of  row U proposals          (K5)
+// which is what the sequential reference code yields for (d,id)-sorted rows, and is
+// deterministic.  The CPU oracle (oracle/orc_build.c) implements the same definition and
+// the two are compared bit for bit.
+//
+//   K3 ph_seed_rows_kernel     generate_layer step 3      lib.rs:719-787 (+choose_n_1 1830-1852)
+//   K5 ph_merge_rows_kernel    the row insertions         lib.rs:797-815, 1118-1147
+//      ph_row_dist_kernel      occupant distances         lib.rs:1128-1133
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "phnsw_device.h"
+
+// ------------------------------------------------------------------ small helpers
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return ph_hip_fail(e, "hipMalloc (build)", __FILE__, __LINE__);
+    }
+    return 0;
+  }
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+
+#define PH_TRY(x)          \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+
+static inline uint64_t stream_next(uint64_t *state) {
+  *state += 0x9E3779B97F4A7C15ULL;
+  return ph_mix64(*state);
+}
+
+// slice.shuffle(rng) shape (Fisher-Yates from the top); stream shared by definition with
+// the oracle.  Replaces thread_rng()/StdRng (lib.rs:832, 1468-1481): "parity unpinned".
+void ph_shuffle_u64(uint64_t *v, uint64_t n, uint64_t seed) {
+  uint64_t st = ph_mix64(seed ^ 0x5851F42D4C957F2DULL);
+  for (uint64_t i = n; i-- > 1;) {
+    uint64_t j = ph_mulhi64(stream_next(&st), i + 1);
+    std::swap(v[i], v[j]);
+  }
+}
+
+// calculate_partitions  lib.rs:1883-1899 (f32 arithmetic as written there)
+static std::vector<uint64_t> calculate_partitions(uint64_t total, uint64_t order) {
+  float lc = ceilf(logf((float)total) / logf((float)order));
+  uint64_t layer_count = (lc != lc || lc < 0.0f) ? 0 : (uint64_t)lc;
+  layer_count = std::max<uint64_t>(1, std::min<uint64_t>(layer_count, PH_MAX_LAYERS));
+  std::vector<uint64_t> p;
+  uint64_t size = total;
+  for (uint64_t i = 0; i < layer_count; i++) {
+    p.push_back(size);
+    size /= order;
+  }
+  std::reverse(p.begin(), p.end());
+  return p;
+}
+
+__device__ __forceinline__ float key_dist(uint64_t key) {
+  uint32_t fk = (uint32_t)(key >> 32);
+  uint32_t u = (fk & 0x80000000u) ? (fk ^ 0x80000000u) : ~fk;
+  return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------ kernels
+
+// search results (VectorIds) -> this layer's NodeIds, self dropped
+// initial_vector_distances + the binary_search map  search.rs:54-62, 73-82
+__global__ void ph_init_from_search_kernel(const uint32_t *nodes, uint32_t n, const uint32_t *vec2node,
+                                           const uint32_t *res_ids, const float *res_d, const uint32_t *res_len,
+                                           uint32_t K, uint32_t *init_ids, float *init_d, uint32_t *init_len,
+                                           uint32_t *bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t self = nodes[i];
+  uint32_t m = 0, len = res_len[i];
+  for (uint32_t k = 0; k < len && k < K; k++) {
+    uint32_t vid = res_ids[(uint64_t)i * K + k];
+    if (vid == self) continue;
+    uint32_t nid = vec2node ? vec2node[vid] : vid;
+    if (nid >= n) {
+      atomicAdd(bad, 1u);
+      continue;
+    }
+    init_ids[(uint64_t)i * K + m] = nid;
+    init_d[(uint64_t)i * K + m] = res_d[(uint64_t)i * K + k];
+    m++;
+  }
+  init_len[i] = m;
+}
+
+struct PhSeedArgs {
+  const float *vecs;
+  uint32_t ld, nv4;
+  int metric;
+  const uint32_t *nodes;  // NodeId -> VectorId of the layer being built
+  uint32_t n, W, K;
+  const uint32_t *init_ids;
+  const float *init_d;
+  const uint32_t *init_len;
+  const uint32_t *gm;      // group members (node ids) in group order
+  const uint32_t *gstart;  // [n+1] per key node; slot n = the None group
+  const uint32_t *gsize;
+  uint64_t layer_count;  // self.layer_count() in the seed expression  lib.rs:729-731
+  uint64_t seed;
+  uint32_t first, count;  // node range handled by this launch
+  uint32_t *rows;
+  float *rows_d;
+};
+
+#define SEED_CMAX 448  // >= 5*64 + 64 + slack
+
+// K3: one wave per node: candidates = supers U picks from the supers' partitions, a
+// distance batch, then sort (d,id) / dedup / drop self / take W  (lib.rs:719-787)
+template <int NV>
+__global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
+  __shared__ uint64_t keys[SEED_CMAX];
+  __shared__ uint64_t sorted[SEED_CMAX];
+  const uint32_t lane = threadIdx.x;
+  const uint64_t lt = lanemask_lt(lane);
+  const bool l2 = a.metric == PHNSW_METRIC_L2;
+  for (uint32_t i = a.first + blockIdx.x; i < a.first + a.count; i += gridDim.x) {
+    const uint32_t self_vec = a.nodes[i];
+    float4 qv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      qv[k] = (c < a.nv4) ? ((const float4 *)(a.vecs + (uint64_t)self_vec * a.ld))[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint32_t len = a.init_len[i];
+    uint32_t sid = 0;
+    float sd = 0.f;
+    uint32_t psz = 0, pst = 0;
+    if (lane < len) {
+      sid = a.init_ids[(uint64_t)i * a.K + lane];
+      sd = a.init_d[(uint64_t)i * a.K + lane];
+      psz = a.gsize[sid];  // filter_map(|n| partition_groups.get(&Some(n)))  lib.rs:735-738
+      pst = a.gstart[sid];
+      keys[lane] = mkkey(sd, sid);  // distances.clone(): the supers are candidates too
+    }
+    uint64_t pm = __ballot(psz > 0);
+    uint32_t size0;
+    uint64_t total = 0;
+    if (pm == 0) {
+      // "probably we're in the top layer. best add ourselves."  lib.rs:739-742 (the None group)
+      pst = a.gstart[a.n];
+      psz = a.gsize[a.n];
+      pm = 1ull;
+      if (lane != 0) psz = 0;
+    }
+    size0 = rl32(psz, __builtin_ctzll(pm));
+    {
+      uint64_t rem = pm;
+      while (rem) {
+        int j = __builtin_ctzll(rem);
+        rem &= rem - 1;
+        total += rl32(psz, j);
+      }
+    }
+    const uint64_t choice_count = std::min<uint64_t>((uint64_t)a.W * 5, total);  // lib.rs:745-746
+    const uint32_t excl = i < size0 ? 1u : 0u;  // choose_n_1 skips (partition 0, index == node_id.0)
+    const uint64_t domain = total - excl;
+    const uint32_t picks = (uint32_t)std::min<uint64_t>(choice_count, domain);
+    const uint64_t rkey =
+        ph_mix64(a.layer_count + (uint64_t)self_vec + (uint64_t)a.n) ^ ph_mix64(a.seed + 0x632BE59BD9B4E019ULL);
+    const uint32_t ncand = len + picks;
+
+    for (uint32_t base = 0; base < picks; base += 64) {
+      uint32_t k = base + lane;
+      bool act = k < picks;
+      uint32_t member = 0, vm = 0;
+      if (act) {
+        uint64_t f = ph_feistel_perm(k, domain, rkey);
+        if (excl && f >= i) f += 1;
+        uint32_t midx = 0;
+        bool found = false;
+        uint64_t rem = pm;
+        while (rem) {
+          int j = __builtin_ctzll(rem);
+          rem &= rem - 1;
+          uint32_t s = rl32(psz, j), st = rl32(pst, j);
+          if (!found) {
+            if (f < s) {
+              midx = st + (uint32_t)f;
+              found = true;
+            } else
+              f -= s;
+          }
+        }
+        member = a.gm[midx];
+        vm = a.nodes[member];
+      } else {
+        // keep the readlane loop wave-uniform: inactive lanes still run it (nothing to do)
+      }
+      // compare_vec(Stored(vector_id), Stored(choice.1))  lib.rs:750-754
+      float myd = 0.f;
+      uint64_t rem = __ballot(act);
+      while (rem) {
+        int l0 = __builtin_ctzll(rem);
+        rem &= rem - 1;
+        int l1 = rem ? __builtin_ctzll(rem) : l0;
+        rem &= rem ? rem - 1 : 0;
+        int l2_ = rem ? __builtin_ctzll(rem) : l0;
+        rem &= rem ? rem - 1 : 0;
+        int l3 = rem ? __builtin_ctzll(rem) : l0;
+        rem &= rem ? rem - 1 : 0;
+        float p0 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l0) * a.ld), qv, a.nv4, lane, l2);
+        float p1 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l1) * a.ld), qv, a.nv4, lane, l2);
+        float p2 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l2_) * a.ld), qv, a.nv4, lane, l2);
+        float p3 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l3) * a.ld), qv, a.nv4, lane, l2);
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
+        p2 = wave_sum(p2);
+        p3 = wave_sum(p3);
+        if ((int)lane == l0) myd = finalize_metric(p0, a.metric);
+        if ((int)lane == l1) myd = finalize_metric(p1, a.metric);
+        if ((int)lane == l2_) myd = finalize_metric(p2, a.metric);
+        if ((int)lane == l3) myd = finalize_metric(p3, a.metric);
+      }
+      if (act) keys[len + k] = mkkey(myd, member);
+    }
+    __syncthreads();
+    // distances.sort_by_key(|d| (OrderedFloat(d.1), d.0))  lib.rs:757 -- rank by counting
+    for (uint32_t c = lane; c < ncand; c += 64) {
+      uint64_t kc = keys[c];
+      uint32_t rank = 0;
+      for (uint32_t e = 0; e < ncand; e++) {
+        uint64_t ke = keys[e];
+        rank += (ke < kc || (ke == kc && e < c)) ? 1u : 0u;
+      }
+      sorted[rank] = kc;
+    }
+    __syncthreads();
+    // dedup(); filter(node_id != n); take(W); pad  lib.rs:758-764
+    uint32_t outn = 0;
+    for (uint32_t base = 0; base < ncand; base += 64) {
+      uint32_t j = base + lane;
+      bool keep = false;
+      uint64_t kj = KEY_NONE;
+      if (j < ncand) {
+        kj = sorted[j];
+        keep = (j == 0 || sorted[j - 1] != kj) && ((uint32_t)kj & IDM) != i;
+      }
+      uint64_t km = __ballot(keep);
+      uint32_t at = outn + __popcll(km & lt);
+      if (keep && at < a.W) {
+        a.rows[(uint64_t)i * a.W + at] = (uint32_t)kj & IDM;
+        a.rows_d[(uint64_t)i * a.W + at] = key_dist(kj);
+      }
+      outn += __popcll(km);
+    }
+    for (uint32_t j = std::min(outn, a.W) + lane; j < a.W; j += 64) {
+      a.rows[(uint64_t)i * a.W + j] = PH_EMPTY32;
+      a.rows_d[(uint64_t)i * a.W + j] = PH_FMAX;
+    }
+    __syncthreads();
+  }
+}
+
+// proposals live in fixed-stride slot arrays: slot (s, k) proposes "insert node s into row
+// tgt[s*S+k] at distance d[s*S+k]" (PH_EMPTY32 = no proposal)
+__global__ void ph_count_targets_kernel(const uint32_t *tgt, uint64_t nslots, uint32_t n, uint32_t *cnt) {
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < nslots; x += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t t = tgt[x];
+    if (t < n) atomicAdd(&cnt[t], 1u);
+  }
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; one block
+__global__ __launch_bounds__(1024) void ph_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *start) {
+  __shared__ uint32_t part[1024];
+  uint32_t t = threadIdx.x;
+  uint64_t chunk = ((uint64_t)n + 1023) / 1024;
+  uint64_t lo = std::min<uint64_t>(t * chunk, n), hi = std::min<uint64_t>(lo + chunk, n);
+  uint32_t s = 0;
+  for (uint64_t i = lo; i < hi; i++) s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (uint64_t i = lo; i < hi; i++) {
+    start[i] = run;
+    run += cnt[i];
+  }
+  if (t == 1023) start[n] = part[1023];
+}
+
+__global__ void ph_fill_targets_kernel(const uint32_t *tgt, const float *d, uint64_t nslots, uint32_t S, uint32_t n,
+                                       const uint32_t *start, uint32_t *cursor, uint32_t *inc_src, float *inc_d) {
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < nslots; x += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t t = tgt[x];
+    if (t < n) {
+      uint32_t at = start[t] + atomicAdd(&cursor[t], 1u);
+      inc_src[at] = (uint32_t)(x / S);
+      inc_d[at] = d[x];
+    }
+  }
+}
+
+// K5: row'[t] = best-W by (d,id) of row[t] U incoming[t]; one wave per target row.
+// The incoming list is unordered (filled with atomics); the result does not depend on it.
+__global__ __launch_bounds__(64) void ph_merge_rows_kernel(uint32_t n, uint32_t W, uint32_t *rows, float *rows_d,
+                                                           const uint32_t *start, const uint32_t *inc_src,
+                                                           const float *inc_d, unsigned long long *added) {
+  __shared__ uint64_t lk[64];
+  __shared__ uint32_t lnew[64];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+    uint32_t s0 = start[t], cnt = start[t + 1] - s0;
+    if (cnt == 0) continue;
+    uint64_t cur = KEY_NONE;
+    uint32_t isnew = 0;
+    if (lane < W) {
+      uint32_t id = rows[(uint64_t)t * W + lane];
+      if (id != PH_EMPTY32) cur = mkkey(rows_d[(uint64_t)t * W + lane], id);
+    }
+    {
+      // rows adopted from elsewhere need not be (d,id)-sorted: order them first
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < W; j++) r += (rl64(cur, j) < cur) ? 1u : 0u;
+      lk[lane] = KEY_NONE;
+      __syncthreads();
+      if (cur != KEY_NONE) lk[r] = cur;
+      __syncthreads();
+      cur = lk[lane];
+      __syncthreads();
+    }
+    for (uint32_t base = 0; base < cnt; base += 64) {
+      uint64_t e = KEY_NONE;
+      if (base + lane < cnt) e = mkkey(inc_d[s0 + base + lane], inc_src[s0 + base + lane]);
+      // against the current row: duplicates (same id => same distance) and rank
+      bool dup = false;
+      uint32_t lt_e = 0;
+      for (uint32_t j = 0; j < W; j++) {
+        uint64_t cj = rl64(cur, j);
+        dup |= (cj == e);
+        lt_e += (cj < e) ? 1u : 0u;
+      }
+      bool valid = e != KEY_NONE && !dup && ((uint32_t)e & IDM) != t;
+      uint64_t vm = __ballot(valid);
+      uint32_t rank_e = 0, shift = 0;
+      uint64_t rem = vm;
+      while (rem) {
+        int j = __builtin_ctzll(rem);
+        rem &= rem - 1;
+        uint64_t ej = rl64(e, j);
+        rank_e += (ej < e) ? 1u : 0u;
+        shift += (ej < cur) ? 1u : 0u;
+      }
+      lk[lane] = KEY_NONE;
+      lnew[lane] = 0;
+      __syncthreads();
+      if (cur != KEY_NONE && lane + shift < W) {
+        lk[lane + shift] = cur;
+        lnew[lane + shift] = isnew;
+      }
+      if (valid && lt_e + rank_e < W) {
+        lk[lt_e + rank_e] = e;
+        lnew[lt_e + rank_e] = 1;
+      }
+      __syncthreads();
+      cur = lk[lane];
+      isnew = lnew[lane];
+      __syncthreads();
+    }
+    if (lane < W) {
+      bool live = cur != KEY_NONE;
+      rows[(uint64_t)t * W + lane] = live ? ((uint32_t)cur & IDM) : PH_EMPTY32;
+      rows_d[(uint64_t)t * W + lane] = live ? key_dist(cur) : PH_FMAX;
+    }
+    uint64_t nm = __ballot(lane < W && cur != KEY_NONE && isnew);
+    if (lane == 0 && nm) atomicAdd(added, (unsigned long long)__popcll(nm));
+  }
+}
+
+// distance of every occupant to its row owner (the values lib.rs:1128-1133 recomputes);
+// one wave per row
+template <int NV>
+__global__ __launch_bounds__(64) void ph_row_dist_kernel(const float *vecs, uint32_t ld, uint32_t nv4, int metric,
+                                                         const uint32_t *nodes, uint32_t n, uint32_t W,
+                                                         const uint32_t *rows, float *rows_d) {
+  const uint32_t lane = threadIdx.x;
+  const bool l2 = metric == PHNSW_METRIC_L2;
+  for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+    float4 qv[NV];
+    const float4 *qrow = (const float4 *)(vecs + (uint64_t)nodes[t] * ld);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      qv[k] = (c < nv4) ? qrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    uint32_t o = lane < W ? rows[(uint64_t)t * W + lane] : PH_EMPTY32;
+    uint32_t vo = o < n ? nodes[o] : 0;
+    float myd = PH_FMAX;
+    uint64_t rem = __ballot(o < n);
+    while (rem) {
+      int j = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      float p = wave_sum(row_partial<NV>((const float4 *)(vecs + (uint64_t)rl32(vo, j) * ld), qv, nv4, lane, l2));
+      if ((int)lane == j) myd = finalize_metric(p, metric);
+    }
+    if (lane < W) rows_d[(uint64_t)t * W + lane] = myd;
+  }
+}
+
+// top-M search results (VectorIds) of node i -> proposals "insert i into row of result k"
+// for (neighbor_vec, distance) in matches.take(M) { if neighbor_vec == vector { break } .. }  lib.rs:1118-1122
+__global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const uint32_t *vec2node,
+                                       const uint32_t *res_ids, const uint32_t *res_len, uint32_t M, uint32_t *tgt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t self = nodes[i], len = res_len[i];
+  bool stop = false;
+  for (uint32_t k = 0; k < M; k++) {
+    uint32_t t = PH_EMPTY32;
+    if (!stop && k < len) {
+      uint32_t vid = res_ids[(uint64_t)i * M + k];
+      if (vid == self)
+        stop = true;
+      else
+        t = vec2node ? vec2node[vid] : vid;
+    }
+    tgt[(uint64_t)i * M + k] = t;
+  }
+}
+
+// ------------------------------------------------------------------ host: shared steps
+
+static int nv_for(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
+
+static uint32_t wave_grid(uint32_t n) {
+  return std::min<uint32_t>(n, 256u * 32u);
+}
+
+// apply proposal slots to the rows of `L`: count, scan, fill, merge (K5)
+static int apply_proposals(PhLayerHost &L, const uint32_t *tgt, const float *d, uint32_t S, uint64_t *out_added) {
+  uint32_t n = L.n_nodes;
+  uint64_t nslots = (uint64_t)n * S;
+  DevBuf<uint32_t> cnt, start, cursor, inc_src;
+  DevBuf<float> inc_d;
+  DevBuf<unsigned long long> added;
+  PH_TRY(cnt.alloc(n + 1));
+  PH_TRY(start.alloc(n + 1));
+  PH_TRY(cursor.alloc(n + 1));
+  PH_TRY(added.alloc(1));
+  PH_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(n + 1) * 4, 0));
+  PH_HIP(hipMemsetAsync(cursor.p, 0, (size_t)(n + 1) * 4, 0));
+  PH_HIP(hipMemsetAsync(added.p, 0, 8, 0));
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((nslots + 255) / 256, 8192);
+  hipLaunchKernelGGL(ph_count_targets_kernel, dim3(blocks), dim3(256), 0, 0, tgt, nslots, n, cnt.p);
+  hipLaunchKernelGGL(ph_scan_kernel, dim3(1), dim3(1024), 0, 0, cnt.p, n, start.p);
+  PH_HIP(hipGetLastError());
+  uint32_t total = 0;
+  PH_HIP(hipMemcpy(&total, start.p + n, 4, hipMemcpyDeviceToHost));
+  PH_TRY(inc_src.alloc(total));
+  PH_TRY(inc_d.alloc(total));
+  hipLaunchKernelGGL(ph_fill_targets_kernel, dim3(blocks), dim3(256), 0, 0, tgt, d, nslots, S, n, start.p, cursor.p,
+                     inc_src.p, inc_d.p);
+  hipLaunchKernelGGL(ph_merge_rows_kernel, dim3(wave_grid(n)), dim3(64), 0, 0, n, L.W, L.neighbors, L.nbr_dist,
+                     start.p, inc_src.p, inc_d.p, added.p);
+  PH_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  PH_HIP(hipMemcpy(&h, added.p, 8, hipMemcpyDeviceToHost));
+  if (out_added) *out_added = h;
+  return 0;
+}
+
+static int ensure_row_dist(phnsw_index *ix, PhLayerHost &L) {
+  if (L.nbr_dist) return 0;
+  const phnsw_store *s = ix->store;
+  PH_HIP(hipMalloc(&L.nbr_dist, (size_t)L.n_nodes * L.W * 4));
+  uint32_t nv4 = s->ld / 4;
+  dim3 g(wave_grid(L.n_nodes)), b(64);
+  switch (nv_for(nv4)) {
+    case 1:
+      hipLaunchKernelGGL(ph_row_dist_kernel<1>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
+                         L.neighbors, L.nbr_dist);
+      break;
+    case 3:
+      hipLaunchKernelGGL(ph_row_dist_kernel<3>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
+                         L.neighbors, L.nbr_dist);
+      break;
+    case 6:
+      hipLaunchKernelGGL(ph_row_dist_kernel<6>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
+                         L.neighbors, L.nbr_dist);
+      break;
+    default:
+      ph_set_error("dim %u unsupported (max 1536)", s->dim);
+      return PHNSW_E_UNSUPPORTED;
+  }
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+// run the batched search for Stored queries and surface per-query failures
+static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32_t nq, const phnsw_search_params *sp,
+                         uint32_t upto, const uint32_t *exclude_dev, uint32_t *out_ids, float *out_d,
+                         uint32_t *out_len, uint32_t out_stride, uint32_t *out_hit) {
+  if (sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
+    ph_set_error("build: search parameters out of range (number_of_candidates 1..1024, probe_depth >= 1)");
+    return PHNSW_E_INVALID;
+  }
+  DevBuf<uint32_t> status;
+  PH_TRY(status.alloc(nq));
+  uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+  for (int attempt = 0; attempt < 3; attempt++) {
+    PH_TRY(ph_search_device(ix, nullptr, 0, qids_dev, nq, sp, upto, exclude_dev, out_ids, out_d, out_len, nullptr,
+                            status.p, ovf_cap, 0, 0, out_stride, out_hit));
+    PH_HIP(hipDeviceSynchronize());
+    std::vector<uint32_t> h(nq);
+    PH_HIP(hipMemcpy(h.data(), status.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    bool overflow = false;
+    for (uint32_t i = 0; i < nq; i++) {
+      if (h[i] == 4) {
+        ph_set_error("build: a candidate vector is missing from a lower layer (layers not nested, lib.rs:261)");
+        return PHNSW_E_MISSING_NODE;
+      }
+      overflow |= (h[i] == 5);
+    }
+    if (!overflow) return 0;
+    ovf_cap *= 8;  // rare: rerun the whole batch with more spill room (results are deterministic)
+  }
+  ph_set_error("build: frontier spill exceeded %u entries", ovf_cap);
+  return PHNSW_E_OVERFLOW;
+}
+
+// ------------------------------------------------------------------ generate_layer
+
+struct HostPair {
+  float d;
+  uint32_t id;
+};
+static inline bool pair_less(const HostPair &a, const HostPair &b) { return a.d < b.d || (a.d == b.d && a.id < b.id); }
+
+// host form of "sort (d,id), dedup, drop self, take W, pad" for the tiny top layer
+static void finish_row_host(std::vector<HostPair> &list, uint32_t self, uint32_t W, uint32_t *ids, float *d) {
+  std::sort(list.begin(), list.end(), pair_less);
+  uint32_t out = 0;
+  for (size_t k = 0; k < list.size() && out < W; k++) {
+    if (k > 0 && list[k].id == list[k - 1].id && list[k].d == list[k - 1].d) continue;
+    if (list[k].id == self) continue;
+    ids[out] = list[k].id;
+    d[out] = list[k].d;
+    out++;
+  }
+  for (; out < W; out++) {
+    ids[out] = PH_EMPTY32;
+    d[out] = PH_FMAX;
+  }
+}
+
+// groups keyed by the nearest super node (lib.rs:711-713); member order = (first distance,
+// node id), the deterministic form of the unstable sort in search.rs:67-69
+static void build_groups(uint32_t n, const std::vector<uint32_t> &key, const std::vector<float> &keyd,
+                         std::vector<uint32_t> &gm, std::vector<uint32_t> &gstart, std::vector<uint32_t> &gsize) {
+  gm.resize(n);
+  std::iota(gm.begin(), gm.end(), 0u);
+  std::sort(gm.begin(), gm.end(), [&](uint32_t x, uint32_t y) {
+    if (key[x] != key[y]) return key[x] < key[y];  // PH_EMPTY32 (None) sorts last
+    if (keyd[x] != keyd[y]) return keyd[x] < keyd[y];
+    return x < y;
+  });
+  gstart.assign(n + 1, 0);
+  gsize.assign(n + 1, 0);
+  for (uint32_t p = 0; p < n; p++) {
+    uint32_t slot = key[gm[p]] == PH_EMPTY32 ? n : key[gm[p]];
+    if (gsize[slot] == 0) gstart[slot] = p;
+    gsize[slot]++;
+  }
+}
+
+// the first layer of a stack has no layers above: compare_all (search.rs:13-30) gives every
+// node all other nodes; n < order here, so the distances come from n K1 launches and the
+// (integer) selection runs on the host
+static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &nodes, uint32_t W,
+                                const phnsw_build_params *bp, std::vector<uint32_t> &rows, std::vector<float> &rows_d) {
+  const phnsw_store *s = ix->store;
+  uint32_t n = (uint32_t)nodes.size();
+  if (n > 16384) {
+    ph_set_error("first layer has %u nodes; the all-pairs seeding (search.rs:46-48) is limited to 16384", n);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  DevBuf<uint32_t> ids;
+  DevBuf<float> out;
+  PH_TRY(ids.alloc(n));
+  PH_TRY(out.alloc((size_t)n * n));
+  PH_HIP(hipMemcpy(ids.p, nodes.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  for (uint32_t i = 0; i < n; i++)
+    PH_TRY(ph_distance_batch(s, s->rows + (uint64_t)nodes[i] * s->ld, ids.p, n, out.p + (size_t)i * n, 0));
+  std::vector<float> D((size_t)n * n);
+  PH_HIP(hipMemcpy(D.data(), out.p, D.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<std::vector<HostPair>> init(n);
+  std::vector<uint32_t> key(n, PH_EMPTY32);
+  std::vector<float> keyd(n, 0.f);
+  for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t j = 0; j < n; j++)
+      if (j != i) init[i].push_back({D[(size_t)i * n + j], j});
+    std::sort(init[i].begin(), init[i].end(), pair_less);
+    if (!init[i].empty()) {
+      key[i] = init[i][0].id;
+      keyd[i] = init[i][0].d;
+    }
+  }
+  std::vector<uint32_t> gm, gstart, gsize;
+  build_groups(n, key, keyd, gm, gstart, gsize);
+  rows.assign((size_t)n * W, PH_EMPTY32);
+  rows_d.assign((size_t)n * W, PH_FMAX);
+  uint64_t layer_count = ix->layers.size();
+  for (uint32_t i = 0; i < n; i++) {
+    std::vector<HostPair> list = init[i];
+    std::vector<std::pair<uint32_t, uint32_t>> parts;
+    uint64_t total = 0;
+    for (auto &p : init[i])
+      if (gsize[p.id]) {
+        parts.push_back({gstart[p.id], gsize[p.id]});
+        total += gsize[p.id];
+      }
+    if (parts.empty()) {
+      uint32_t slot = init[i].empty() ? n : init[i][0].id;
+      parts.push_back({gstart[slot], gsize[slot]});
+      total = gsize[slot];
+    }
+    uint64_t choice_count = std::min<uint64_t>((uint64_t)W * 5, total);
+    uint64_t excl = i < parts[0].second ? 1 : 0;
+    uint64_t domain = total - excl;
+    uint64_t picks = std::min(choice_count, domain);
+    uint64_t rkey = ph_mix64(layer_count + (uint64_t)nodes[i] + (uint64_t)n) ^ ph_mix64(bp->seed + 0x632BE59BD9B4E019ULL);
+    for (uint64_t k = 0; k < picks; k++) {
+      uint64_t f = ph_feistel_perm(k, domain, rkey);
+      if (excl && f >= i) f += 1;
+      size_t p = 0;
+      while (f >= parts[p].second) {
+        f -= parts[p].second;
+        p++;
+      }
+      uint32_t member = gm[parts[p].first + f];
+      list.push_back({D[(size_t)i * n + member], member});
+    }
+    finish_row_host(list, i, W, &rows[(size_t)i * W], &rows_d[(size_t)i * W]);
+  }
+  return 0;
+}
+
+static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
+                               const phnsw_build_params *bp) {
+  const phnsw_store *s = ix->store;
+  if (!vids || n64 == 0 || W64 == 0 || W64 > 64 || n64 >= 0x7FFFFFFFull || !bp) {
+    ph_set_error("generate_layer: need 1 <= n < 2^31 nodes and 1 <= neighborhood_size <= 64");
+    return PHNSW_E_INVALID;
+  }
+  if (ix->layers.size() >= PH_MAX_LAYERS) {
+    ph_set_error("generate_layer: more than %d layers", PH_MAX_LAYERS);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  if (nv_for(s->ld / 4) == 0) {
+    ph_set_error("dim %u unsupported (max 1536)", s->dim);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  uint32_t n = (uint32_t)n64, W = (uint32_t)W64;
+  std::vector<uint32_t> nodes(n);
+  for (uint32_t i = 0; i < n; i++) {
+    if (vids[i] >= s->n) {
+      ph_set_error("generate_layer: VectorId %llu outside the store", (unsigned long long)vids[i]);
+      return PHNSW_E_INVALID;
+    }
+    nodes[i] = (uint32_t)vids[i];
+  }
+  std::sort(nodes.begin(), nodes.end());  // vs.sort()  lib.rs:685
+  for (uint32_t i = 1; i < n; i++)
+    if (nodes[i] == nodes[i - 1]) {
+      ph_set_error("generate_layer: duplicate VectorId %u", nodes[i]);
+      return PHNSW_E_INVALID;
+    }
+  // the new layer object: nodes + id map first (the seeding kernels need them), rows later
+  std::vector<uint32_t> empty_rows((size_t)n * W, PH_EMPTY32);
+  PhLayerHost L;
+  PH_TRY(ph_layer_upload(ix, nodes.data(), empty_rows.data(), n, W, &L));
+  hipError_t e = hipMalloc(&L.nbr_dist, (size_t)n * W * 4);
+  if (e != hipSuccess) {
+    ph_layer_free(L);
+    return ph_hip_fail(e, "nbr_dist alloc", __FILE__, __LINE__);
+  }
+  int rc = 0;
+  if (ix->layers.empty()) {
+    std::vector<uint32_t> rows;
+    std::vector<float> rows_d;
+    rc = generate_first_layer(ix, nodes, W, bp, rows, rows_d);
+    if (!rc) {
+      e = hipMemcpy(L.neighbors, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(L.nbr_dist, rows_d.data(), rows_d.size() * 4, hipMemcpyHostToDevice);
+      if (e != hipSuccess) rc = ph_hip_fail(e, "first layer upload", __FILE__, __LINE__);
+    }
+  } else {
+    const phnsw_search_params ips = bp->initial_partition_search;
+    const uint32_t K = (uint32_t)ips.number_of_candidates;
+    if (K == 0 || K > 64) {
+      ph_set_error("initial_partition_search.number_of_candidates must be 1..64 (got %u)", K);
+      rc = PHNSW_E_UNSUPPORTED;
+    }
+    DevBuf<uint32_t> res_ids, res_len, init_ids, init_len, bad, d_gm, d_gstart, d_gsize;
+    DevBuf<float> res_d, init_d;
+    if (!rc) rc = res_ids.alloc((size_t)n * K);
+    if (!rc) rc = res_d.alloc((size_t)n * K);
+    if (!rc) rc = res_len.alloc(n);
+    if (!rc) rc = init_ids.alloc((size_t)n * K);
+    if (!rc) rc = init_d.alloc((size_t)n * K);
+    if (!rc) rc = init_len.alloc(n);
+    if (!rc) rc = bad.alloc(1);
+    // 1. generate_initial_partitions: search the layers above for every node  search.rs:32-71
+    if (!rc) rc = search_stored(ix, L.nodes, n, &ips, 0, nullptr, res_ids.p, res_d.p, res_len.p, 0, nullptr);
+    std::vector<uint32_t> key(n), h_len(n);
+    std::vector<float> keyd(n);
+    if (!rc) {
+      hipMemsetAsync(bad.p, 0, 4, 0);
+      hipLaunchKernelGGL(ph_init_from_search_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
+                         L.identity ? nullptr : L.vec2node, res_ids.p, res_d.p, res_len.p, K, init_ids.p, init_d.p,
+                         init_len.p, bad.p);
+      uint32_t hbad = 0;
+      e = hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(h_len.data(), init_len.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+      // first (nearest) super of every node: column 0 of the init lists
+      if (e == hipSuccess)
+        e = hipMemcpy2D(key.data(), 4, init_ids.p, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost);
+      if (e == hipSuccess)
+        e = hipMemcpy2D(keyd.data(), 4, init_d.p, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost);
+      if (e != hipSuccess)
+        rc = ph_hip_fail(e, "init readback", __FILE__, __LINE__);
+      else if (hbad) {
+        ph_set_error("generate_layer: %u search results are not nodes of the new layer (layers must be nested)", hbad);
+        rc = PHNSW_E_MISSING_NODE;
+      }
+    }
+    if (!rc) {
+      // 2. partition groups  lib.rs:711-713
+      for (uint32_t i = 0; i < n; i++)
+        if (h_len[i] == 0) {
+          key[i] = PH_EMPTY32;
+          keyd[i] = 0.f;
+        }
+      std::vector<uint32_t> gm, gstart, gsize;
+      build_groups(n, key, keyd, gm, gstart, gsize);
+      rc = d_gm.alloc(n);
+      if (!rc) rc = d_gstart.alloc(n + 1);
+      if (!rc) rc = d_gsize.alloc(n + 1);
+      if (!rc) {
+        e = hipMemcpy(d_gm.p, gm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_gstart.p, gstart.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_gsize.p, gsize.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = ph_hip_fail(e, "group upload", __FILE__, __LINE__);
+      }
+    }
+    if (!rc) {
+      // 3. neighbourhood seeding (K3)
+      PhSeedArgs a;
+      a.vecs = s->rows;
+      a.ld = s->ld;
+      a.nv4 = s->ld / 4;
+      a.metric = s->metric;
+      a.nodes = L.nodes;
+      a.n = n;
+      a.W = W;
+      a.K = K;
+      a.init_ids = init_ids.p;
+      a.init_d = init_d.p;
+      a.init_len = init_len.p;
+      a.gm = d_gm.p;
+      a.gstart = d_gstart.p;
+      a.gsize = d_gsize.p;
+      a.layer_count = ix->layers.size();
+      a.seed = bp->seed;
+      a.first = 0;
+      a.count = n;
+      a.rows = L.neighbors;
+      a.rows_d = L.nbr_dist;
+      dim3 g(wave_grid(n)), b(64);
+      switch (nv_for(a.nv4)) {
+        case 1:
+          hipLaunchKernelGGL(ph_seed_rows_kernel<1>, g, b, 0, 0, a);
+          break;
+        case 3:
+          hipLaunchKernelGGL(ph_seed_rows_kernel<3>, g, b, 0, 0, a);
+          break;
+        default:
+          hipLaunchKernelGGL(ph_seed_rows_kernel<6>, g, b, 0, 0, a);
+          break;
+      }
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) rc = ph_hip_fail(e, "seed rows", __FILE__, __LINE__);
+    }
+  }
+  if (!rc) {
+    // 4. make neighbourhoods bidirectional  lib.rs:789-815: every row entry (t, d) of node i
+    // proposes (i, d) to row t; evaluated against the snapshot
+    DevBuf<uint32_t> snap;
+    DevBuf<float> snap_d;
+    rc = snap.alloc((size_t)n * W);
+    if (!rc) rc = snap_d.alloc((size_t)n * W);
+    if (!rc) {
+      e = hipMemcpy(snap.p, L.neighbors, (size_t)n * W * 4, hipMemcpyDeviceToDevice);
+      if (e == hipSuccess) e = hipMemcpy(snap_d.p, L.nbr_dist, (size_t)n * W * 4, hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) rc = ph_hip_fail(e, "snapshot", __FILE__, __LINE__);
+    }
+    if (!rc) rc = apply_proposals(L, snap.p, snap_d.p, W, nullptr);
+  }
+  if (rc) {
+    ph_layer_free(L);
+    return rc;
+  }
+  ix->layers.push_back(L);
+  return 0;
+}
+
+// ------------------------------------------------------------------ link / recall / improve
+
+// link_nodes_in_layer_to_better_neighbors over all nodes  lib.rs:1070-1154
+static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp, uint64_t link_count,
+                           uint64_t *out_added) {
+  if (lft >= ix->layers.size() || link_count == 0 || link_count > sp->number_of_candidates) {
+    ph_set_error("link_layer: layer %u out of range or link_count %llu not in 1..number_of_candidates", lft,
+                 (unsigned long long)link_count);
+    return PHNSW_E_INVALID;
+  }
+  PhLayerHost &L = ix->layers[lft];
+  PH_TRY(ensure_row_dist(ix, L));
+  uint32_t n = L.n_nodes, M = (uint32_t)link_count;
+  DevBuf<uint32_t> res_ids, res_len, tgt;
+  DevBuf<float> res_d;
+  PH_TRY(res_ids.alloc((size_t)n * M));
+  PH_TRY(res_d.alloc((size_t)n * M));
+  PH_TRY(res_len.alloc(n));
+  PH_TRY(tgt.alloc((size_t)n * M));
+  // search_layers(Stored(vector), sp, &pseudo_stack, Some(vector)): the rows are only
+  // rewritten after every search has finished, which is the clone of lib.rs:1097-1100
+  PH_TRY(search_stored(ix, L.nodes, n, sp, lft + 1, L.nodes, res_ids.p, res_d.p, res_len.p, M, nullptr));
+  hipLaunchKernelGGL(ph_link_targets_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
+                     L.identity ? nullptr : L.vec2node, res_ids.p, res_len.p, M, tgt.p);
+  PH_HIP(hipGetLastError());
+  return apply_proposals(L, tgt.p, res_d.p, M, out_added);
+}
+
+// stochastic_recall_at  lib.rs:1463-1499
+static int recall_impl(phnsw_index *ix, uint32_t at, const phnsw_optimization_params *op, float *out) {
+  if (at >= ix->layers.size()) {
+    ph_set_error("stochastic_recall_at: layer %u out of range", at);
+    return PHNSW_E_INVALID;
+  }
+  const PhLayerHost &L = ix->layers[at];
+  uint64_t total = L.n_nodes;
+  uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
+  selection = std::min<uint64_t>(std::max<uint64_t>(selection, 1), total);
+  std::vector<uint32_t> h_nodes(total);
+  PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, total * 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> vecs(h_nodes.begin(), h_nodes.end());
+  if (selection != total) ph_shuffle_u64(vecs.data(), total, 42);  // StdRng::seed_from_u64(42)
+  std::vector<uint32_t> q(selection);
+  for (uint64_t i = 0; i < selection; i++) q[i] = (uint32_t)vecs[i];
+  uint32_t nq = (uint32_t)selection;
+  DevBuf<uint32_t> qd, ids, len, hit;
+  DevBuf<float> d;
+  PH_TRY(qd.alloc(nq));
+  PH_TRY(ids.alloc(nq));
+  PH_TRY(d.alloc(nq));
+  PH_TRY(len.alloc(nq));
+  PH_TRY(hit.alloc(nq));
+  PH_HIP(hipMemcpy(qd.p, q.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  // self.search(Stored(vid), op.search): the whole stack  lib.rs:1488-1491
+  PH_TRY(search_stored(ix, qd.p, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
+  std::vector<uint32_t> h(nq);
+  PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  uint64_t relevant = 0;
+  for (uint32_t x : h) relevant += x;
+  *out = (float)relevant / (float)selection;
+  return 0;
+}
+
+// improve_neighbors_upto  lib.rs:1515-1544
+static int improve_neighbors_upto_impl(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp, float last_recall,
+                                       float *out) {
+  if (upto < 1 || upto > ix->layers.size()) {
+    ph_set_error("improve_neighbors_upto: upto %u out of range", upto);
+    return PHNSW_E_INVALID;
+  }
+  const phnsw_optimization_params *op = &bp->optimization;
+  float last = (last_recall != last_recall) ? 0.0f : last_recall;
+  float improvement = 1.0f;
+  uint64_t rounds = 0;
+  while (improvement >= op->neighborhood_threshold && last < 1.0f) {
+    for (uint32_t lft = 0; lft < upto; lft++) PH_TRY(link_layer_impl(ix, lft, &op->search, bp->neighborhood_size, nullptr));
+    float recall = 0.f;
+    PH_TRY(recall_impl(ix, upto - 1, op, &recall));
+    improvement = recall - last;
+    last = recall;
+    rounds++;
+    if (bp->max_link_rounds && rounds >= bp->max_link_rounds) break;
+  }
+  *out = last;
+  return 0;
+}
+
+// improve_index_at  lib.rs:1546-1603 with promote_at_layer treated as "did not promote"
+static int improve_index_at_impl(phnsw_index *ix, uint32_t lft, const phnsw_build_params *bp, float *out) {
+  const phnsw_optimization_params *op = &bp->optimization;
+  float recall = 0.f;
+  PH_TRY(recall_impl(ix, lft, op, &recall));
+  float improvement = 1.0f;
+  int bailout = 1;
+  while (improvement >= op->promotion_threshold && recall < 1.0f && bailout != 0) {
+    float last = recall;
+    uint32_t cur = 0;
+    while (cur <= lft && bailout != 0) {
+      PH_TRY(improve_neighbors_upto_impl(ix, cur + 1, bp, NAN, &recall));
+      cur++;
+    }
+    bailout--;
+    improvement = recall - last;
+  }
+  *out = recall;
+  return 0;
+}
+
+static int improve_index_impl(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb, void *user,
+                              float *out) {
+  if (ix->layers.empty()) {
+    ph_set_error("improve_index: index has no layers");
+    return PHNSW_E_INVALID;
+  }
+  float recall = 0.f;
+  PH_TRY(recall_impl(ix, (uint32_t)ix->layers.size() - 1, &bp->optimization, &recall));
+  for (uint32_t lft = 0; lft < ix->layers.size(); lft++) {
+    PH_TRY(improve_index_at_impl(ix, lft, bp, &recall));
+    if (cb && cb(user, "improve_index", lft + 1, ix->layers.size())) {
+      ph_set_error("interrupted by the progress callback");
+      return PHNSW_E_INVALID;
+    }
+  }
+  if (out) *out = recall;
+  return 0;
+}
+
+// ------------------------------------------------------------------ C ABI
+
+static int enter(const phnsw_index *ix) {
+  if (!ix) {
+    ph_set_error("null index");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(ix->store->device));
+  return 0;
+}
+
+extern "C" int phnsw_generate_layer(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
+                                    const phnsw_build_params *bp) {
+  PH_TRY(enter(ix));
+  return generate_layer_impl(ix, vids, n, neighborhood_size, bp);
+}
+
+extern "C" int phnsw_link_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                                uint64_t link_count, uint64_t *out_added) {
+  PH_TRY(enter(ix));
+  if (!sp) return PHNSW_E_INVALID;
+  return link_layer_impl(ix, layer_from_top, sp, link_count, out_added);
+}
+
+extern "C" int phnsw_stochastic_recall_at(phnsw_index *ix, uint32_t layer_from_top,
+                                          const phnsw_optimization_params *op, float *out_recall) {
+  PH_TRY(enter(ix));
+  if (!op || !out_recall) return PHNSW_E_INVALID;
+  return recall_impl(ix, layer_from_top, op, out_recall);
+}
+
+extern "C" int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
+                                            float last_recall, float *out_recall) {
+  PH_TRY(enter(ix));
+  if (!bp || !out_recall) return PHNSW_E_INVALID;
+  return improve_neighbors_upto_impl(ix, upto, bp, last_recall, out_recall);
+}
+
+extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb, void *user,
+                                   float *out_recall) {
+  PH_TRY(enter(ix));
+  if (!bp) return PHNSW_E_INVALID;
+  return improve_index_impl(ix, bp, cb, user, out_recall);
+}
+
+// Hnsw::generate  lib.rs:825-893
+extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                           phnsw_progress_cb cb, void *user, phnsw_index **out) {
+  if (!s || !vids || !bp || !out || n == 0 || bp->order < 2) {
+    ph_set_error("phnsw_build: invalid argument (need n > 0, order >= 2)");  // assert!(total_size > 0) lib.rs:837
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  phnsw_index *ix = new phnsw_index();
+  ix->store = s;
+  s->refcount++;
+  ix->bp = *bp;
+  std::vector<uint64_t> vs(vids, vids + n);
+  ph_shuffle_u64(vs.data(), n, bp->seed);  // vs.shuffle(&mut thread_rng())  lib.rs:832-833
+  std::vector<uint64_t> parts = calculate_partitions(n, bp->order);
+  for (size_t i = 0; i < parts.size(); i++) {
+    uint64_t length = std::min<uint64_t>(parts[i], n);  // lib.rs:858-860
+    size_t level = parts.size() - i - 1;
+    uint64_t W = level == 0 ? bp->zero_layer_neighborhood_size : bp->neighborhood_size;
+    int rc = generate_layer_impl(ix, vs.data(), length, W, bp);
+    if (!rc) rc = improve_index_impl(ix, bp, nullptr, nullptr, nullptr);  // lib.rs:877
+    if (!rc && cb && cb(user, "generate", i + 1, parts.size())) {
+      ph_set_error("interrupted by the progress callback");
+      rc = PHNSW_E_INVALID;
+    }
+    if (rc) {
+      phnsw_index_destroy(ix);
+      return rc;
+    }
+  }
+  *out = ix;
+  return 0;
+}

@@ -99,7 +99,18 @@ struct PhSearchArgs {
   uint32_t *counter;
   // knn mode (Hnsw::knn lib.rs:905-928): bottom layer only, query = node, seed (node, 0.0)
   uint32_t knn_mode;
+  uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
+  uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
 };
+
+void ph_layer_free(PhLayerHost &l);
+int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
+                    PhLayerHost *out);
+int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
+                     uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
+                     uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
+                     uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride = 0,
+                     uint32_t *out_hit = nullptr);
 
 // launchers (search.hip)
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream);

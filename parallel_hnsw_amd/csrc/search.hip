@@ -441,9 +441,21 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       clen = 0;
     }
     // (candidates.iter().collect(), ..)  search.rs:139
-    for (uint32_t i = lane; i < ef; i += 64) {
-      a.out_ids[(uint64_t)q * ef + i] = i < clen ? Cid[i] : PH_EMPTY32;
-      a.out_d[(uint64_t)q * ef + i] = i < clen ? Cd[i] : PH_FMAX;
+    const uint32_t ostride = a.out_stride ? a.out_stride : ef;
+    for (uint32_t i = lane; i < ostride; i += 64) {
+      a.out_ids[(uint64_t)q * ostride + i] = i < clen ? Cid[i] : PH_EMPTY32;
+      a.out_d[(uint64_t)q * ostride + i] = i < clen ? Cd[i] : PH_FMAX;
+    }
+    if (a.out_hit) {
+      // res.iter().any(|v| v == *vid)  lib.rs:1492
+      bool hit = false;
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t i = lane + 64u * c;
+        hit |= (i < clen && Cid[i] == qvec);
+      }
+      uint64_t hm = __ballot(hit);
+      if (lane == 0) a.out_hit[q] = hm ? 1u : 0u;
     }
     if (lane == 0) {
       a.out_len[q] = clen;

@@ -1,0 +1,144 @@
+"""GPU parity for index construction: Hnsw::generate / generate_layer / link rounds /
+stochastic recall through the C ABI against the oracle's deterministic build on the same
+seeded inputs.  Graphs (integer work) must be identical, recall values equal."""
+import numpy as np
+import pytest
+
+import oracle
+import parallel_hnsw_amd as ph
+from helpers import EMPTY, load, toy_vectors
+
+pytestmark = pytest.mark.gpu
+
+TOY = load("toy_index.json")
+
+
+def layers_equal(gix, oix):
+    assert gix.layer_count() == oix.layer_count
+    for l in range(oix.layer_count):
+        onodes, onb = oix.layer(l)
+        gl = gix._layer(l)
+        np.testing.assert_array_equal(gl.nodes, onodes)
+        np.testing.assert_array_equal(gl.neighbors, onb, err_msg="layer %d" % l)
+
+
+def obp(**kw):
+    return oracle.default_build_params(**kw)
+
+
+def gbp(**kw):
+    return ph.BuildParameters(**kw)
+
+
+@pytest.mark.parametrize("n,dim,metric,kw", [
+    (600, 16, 0, dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12)),
+    (3000, 32, 0, dict()),
+    (3000, 100, 0, dict(seed=5)),
+    (2500, 32, 2, dict(seed=1)),                      # Euclidean comparator (lib.rs:2422-2441)
+    (1500, 768, 0, dict(order=24)),
+    (300, 8, 1, dict(order=400)),                     # single layer: all-pairs seeding only
+])
+def test_generate_parity(n, dim, metric, kw):
+    normalize = metric != 2
+    rows = oracle.synth_rows(0, n, dim, normalize=normalize)
+    oix = oracle.Index.generate(rows, np.arange(n), obp(**kw), dim=dim, metric=metric,
+                                sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim], metric=metric)
+    gix = ph.Hnsw.generate(store, np.arange(n), gbp(**kw))
+    layers_equal(gix, oix)
+    assert oix.check_layer_invariants() == 0
+    # same recall estimate (lib.rs:1463-1499)
+    op = obp(**kw).optimization
+    assert gix.stochastic_recall() == pytest.approx(oix.stochastic_recall_at(oix.layer_count - 1, op), abs=0)
+
+
+def test_generate_subset_of_store_and_synthetic_store():
+    """vids need not cover the store; the store can be generated on the device"""
+    n, dim = 4000, 64
+    rows = oracle.synth_rows(0, n, dim)
+    vids = np.arange(0, n, 3)
+    oix = oracle.Index.generate(rows, vids, obp(seed=3), dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    gix = ph.Hnsw.generate(store, vids, gbp(seed=3))
+    layers_equal(gix, oix)
+
+
+def test_link_round_and_recall_parity_on_adopted_graph():
+    """phnsw_index_from_layers + link rounds: rows come without stored distances"""
+    n, dim = 3000, 48
+    rows = oracle.synth_rows(0, n, dim)
+    bp = obp(max_link_rounds=1)
+    oix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    oix.set_sum_mode(oracle.SUM_BLOCKED64)
+    vs = oracle.shuffle(np.arange(n), 9)
+    sizes = oracle.calculate_partitions(n, 12)
+    for i, sz in enumerate(sizes):
+        oix.generate_layer(vs[:sz], 48 if i == len(sizes) - 1 else 24, bp)
+    store = ph.VectorStore(rows[:, :dim])
+    gix = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)], gbp(max_link_rounds=1))
+    layers_equal(gix, oix)
+    sp = (300, 300, 2)
+    for lft in range(oix.layer_count):
+        oa = oix.link_layer(lft, sp, 24)
+        ga = gix.link_layer_to_better_neighbors(lft, ph.SearchParameters(*sp))
+        assert ga == oa
+        layers_equal(gix, oix)
+    op = bp.optimization
+    for lft in range(oix.layer_count):
+        assert gix.stochastic_recall_at(lft) == oix.stochastic_recall_at(lft, op)
+    r_o = oix.improve_index(bp)
+    r_g = gix.improve_index()
+    assert r_g == r_o
+    layers_equal(gix, oix)
+
+
+def test_generate_layer_stepwise_parity():
+    n, dim = 2000, 24
+    rows = oracle.synth_rows(0, n, dim)
+    bp_o, bp_g = obp(seed=11), gbp(seed=11)
+    oix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    oix.set_sum_mode(oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim])
+    vs = oracle.shuffle(np.arange(n), 11)
+    sizes = oracle.calculate_partitions(n, 12)
+    oix.generate_layer(vs[:sizes[0]], 24, bp_o)
+    gix = ph.Hnsw.from_layers(store, [oix.layer(0)], bp_g)
+    for i, sz in enumerate(sizes[1:], 1):
+        W = 48 if i == len(sizes) - 1 else 24
+        oix.generate_layer(vs[:sz], W, bp_o)
+        gix.generate_layer(vs[:sz], W)
+        layers_equal(gix, oix)
+
+
+def test_toy_index_properties():
+    """make_simple_hnsw (lib.rs:1994-2015) built on the GPU: test_search / small improvement"""
+    b = TOY["vectors"]["build"]
+    data = toy_vectors()
+    store = ph.VectorStore(data, metric=ph.METRIC_ONE_MINUS_DOT)
+    for seed in (0, 1, 7):
+        bp = gbp(order=b["order"], neighborhood_size=3, zero_layer_neighborhood_size=6, seed=seed)
+        h = ph.Hnsw.generate(store, np.arange(9), bp)
+        assert h.layer_count() == 2
+        assert list(h.get_layer(0).nodes) == list(range(9))
+        h.improve_index()
+        for i in range(9):
+            res = h.search(ph.Unstored(data[i]), ph.SearchParameters())
+            assert res[0][0] == i  # test_small_index_improvement lib.rs:2270-2284
+        obp_ = oracle.default_build_params(order=b["order"], neighborhood_size=3, zero_layer_neighborhood_size=6,
+                                           seed=seed)
+        oix = oracle.Index.generate(data, list(range(9)), obp_, metric=oracle.METRIC_ONE_MINUS_DOT,
+                                    sum_mode=oracle.SUM_BLOCKED64, threads=1)
+        layers_equal(h, oix)
+
+
+def test_build_rejects_bad_input():
+    data = toy_vectors()
+    store = ph.VectorStore(data, metric=ph.METRIC_ONE_MINUS_DOT)
+    with pytest.raises(ph.PhnswError):
+        ph.Hnsw.generate(store, np.array([], dtype=np.uint64), gbp())   # assert!(total_size > 0) lib.rs:837
+    with pytest.raises(ph.PhnswError):
+        ph.Hnsw.generate(store, np.array([0, 1, 99], dtype=np.uint64), gbp())
+    with pytest.raises(ph.PhnswError):
+        ph.Hnsw.generate(store, np.array([0, 1, 1], dtype=np.uint64), gbp(order=2))
+    with pytest.raises(ph.PhnswError):
+        ph.Hnsw.generate(store, np.arange(9), gbp(zero_layer_neighborhood_size=65))
