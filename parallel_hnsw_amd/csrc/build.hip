@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -53,6 +55,25 @@ struct DevBuf {
     int rc__ = (x);        \
     if (rc__) return rc__; \
   } while (0)
+
+#include <chrono>
+static bool ph_verbose() {
+  static int v = -1;
+  if (v < 0) v = getenv("PHNSW_VERBOSE") ? 1 : 0;
+  return v == 1;
+}
+struct PhTimer {
+  const char *what;
+  uint64_t n;
+  std::chrono::steady_clock::time_point t0;
+  PhTimer(const char *w, uint64_t n_) : what(w), n(n_), t0(std::chrono::steady_clock::now()) {}
+  ~PhTimer() {
+    if (!ph_verbose()) return;
+    hipDeviceSynchronize();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[phnsw] %-28s n=%-9llu %.3f s\n", what, (unsigned long long)n, s);
+  }
+};
 
 static inline uint64_t stream_next(uint64_t *state) {
   *state += 0x9E3779B97F4A7C15ULL;
@@ -690,6 +711,7 @@ static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n
     return PHNSW_E_UNSUPPORTED;
   }
   uint32_t n = (uint32_t)n64, W = (uint32_t)W64;
+  PhTimer tm("generate_layer", n);
   std::vector<uint32_t> nodes(n);
   for (uint32_t i = 0; i < n; i++) {
     if (vids[i] >= s->n) {
@@ -855,6 +877,7 @@ static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_par
     return PHNSW_E_INVALID;
   }
   PhLayerHost &L = ix->layers[lft];
+  PhTimer tm("link_layer", L.n_nodes);
   PH_TRY(ensure_row_dist(ix, L));
   uint32_t n = L.n_nodes, M = (uint32_t)link_count;
   DevBuf<uint32_t> res_ids, res_len, tgt;
@@ -879,6 +902,7 @@ static int recall_impl(phnsw_index *ix, uint32_t at, const phnsw_optimization_pa
     return PHNSW_E_INVALID;
   }
   const PhLayerHost &L = ix->layers[at];
+  PhTimer tm("stochastic_recall_at", L.n_nodes);
   uint64_t total = L.n_nodes;
   uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
   selection = std::min<uint64_t>(std::max<uint64_t>(selection, 1), total);
@@ -925,6 +949,7 @@ static int improve_neighbors_upto_impl(phnsw_index *ix, uint32_t upto, const phn
     improvement = recall - last;
     last = recall;
     rounds++;
+    if (ph_verbose()) fprintf(stderr, "[phnsw] improve_neighbors_upto(%u) round %llu recall %.4f\n", upto, (unsigned long long)rounds, recall);
     if (bp->max_link_rounds && rounds >= bp->max_link_rounds) break;
   }
   *out = last;
