@@ -92,6 +92,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libphnsw.so is not built (run `python __graft_entry__.py` or "
                               "`make -C parallel_hnsw_amd/csrc`); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If it is
+        # importable, load it first so that libphnsw binds to that copy (same soname) instead
+        # of bringing /opt/rocm's into the process next to it -- with two runtimes the second
+        # one finds no GPU.
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
