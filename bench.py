@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json): batched greedy HNSW search on
+1M x 768 f32 vectors, queries/sec at recall@10 >= 0.95, one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the search kernel over one batch of --nq synthetic queries per GPU,
+inputs already resident in HBM.  Every rank holds the full store and graph (search
+replicates, north_star) and searches its own query batch: weak scaling, no data-path
+collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+
+class _DevArray:
+    """expose a raw device pointer to torch (zero copy) via __cuda_array_interface__"""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--dataset", default="clustered", choices=["clustered", "iid"])
+    ap.add_argument("--ef", type=int, default=0, help="fix number_of_candidates (0 = sweep for recall@10>=0.95)")
+    ap.add_argument("--probe-depth", type=int, default=0)
+    ap.add_argument("--target-recall", type=float, default=0.95)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-iid", action="store_true", help="skip the secondary iid-uniform measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import parallel_hnsw_amd as ph
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def log(*a):
+        if rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    def make_store(kind, n, first):
+        if kind == "clustered":
+            return ph.VectorStore.clustered(n, args.dim, seed=42, first=first, n_clusters=1000, noise=1.0, device=local)
+        return ph.VectorStore.synthetic(n, args.dim, seed=42, first=first, device=local)
+
+    def tensor_of(store):
+        return torch.as_tensor(_DevArray(store.rows_dev, (store.n, store.ld)), device=dev)
+
+    def ground_truth(base_t, q_t, k=10):
+        best_v = torch.full((q_t.shape[0], k), -2.0, device=dev)
+        best_i = torch.zeros((q_t.shape[0], k), dtype=torch.int64, device=dev)
+        step_b = 250_000
+        for qs in range(0, q_t.shape[0], 2000):
+            qq = q_t[qs:qs + 2000]
+            for bs in range(0, base_t.shape[0], step_b):
+                sc = qq @ base_t[bs:bs + step_b].T
+                v, i = torch.topk(sc, min(k, sc.shape[1]), dim=1)
+                allv = torch.cat([best_v[qs:qs + 2000], v], 1)
+                alli = torch.cat([best_i[qs:qs + 2000], i + bs], 1)
+                tv, ti = torch.topk(allv, k, dim=1)
+                best_v[qs:qs + 2000] = tv
+                best_i[qs:qs + 2000] = torch.gather(alli, 1, ti)
+        return best_i
+
+    def recall_at_10(ids_t, gt_t):
+        hit = (ids_t[:, :10, None].to(torch.int64) == gt_t[:, None, :]).any(2).float().sum(1) / 10.0
+        return float(hit.mean())
+
+    class Runner:
+        """owns the device output buffers of one query batch"""
+
+        def __init__(self, index, q_store, ef_max=1024):
+            self.ix = index
+            self.q = q_store
+            nq = q_store.n
+            self.ids = torch.empty((nq, ef_max), dtype=torch.int32, device=dev)
+            self.d = torch.empty((nq, ef_max), dtype=torch.float32, device=dev)
+            self.len = torch.empty(nq, dtype=torch.int32, device=dev)
+            self.stats = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+            self.status = torch.empty(nq, dtype=torch.int32, device=dev)
+
+        def launch(self, sp):
+            self.ix.search_batch_device(self.q.n, sp, self.ids.data_ptr(), self.d.data_ptr(), self.len.data_ptr(),
+                                        self.status.data_ptr(), queries=self.q.rows_dev, ldq=self.q.ld,
+                                        out_stats=self.stats.data_ptr(), stream=stream)
+
+        def result_ids(self, ef):
+            return self.ids.view(-1)[: self.q.n * ef].view(self.q.n, ef)
+
+    def measure_dataset(kind, headline):
+        t0 = time.time()
+        store = make_store(kind, args.n, 0)
+        torch.cuda.synchronize()
+        log("%s store %d x %d generated in %.1f s" % (kind, args.n, args.dim, time.time() - t0))
+        bp = ph.BuildParameters()
+        t0 = time.time()
+        index = ph.Hnsw.generate(store, np.arange(args.n, dtype=np.uint64), bp)
+        torch.cuda.synchronize()
+        build_s = time.time() - t0
+        log("index built in %.1f s (%.0f vectors/s), layers %s" % (
+            build_s, args.n / build_s, [index._layer(l).node_count() for l in range(index.layer_count())]))
+        base_t = tensor_of(store)
+        # calibration queries are the same on every rank => every rank picks the same parameters
+        cal = make_store(kind, 2000, 2 ** 33)
+        cal_gt = ground_truth(base_t, tensor_of(cal))
+        cal_run = Runner(index, cal)
+        if args.ef:
+            grid = [(args.ef, args.probe_depth or 2)]
+        else:
+            grid = [(64, 2), (128, 2), (128, 4), (128, 8), (200, 4), (300, 2), (300, 4), (200, 8), (300, 8),
+                    (128, 16), (300, 16), (512, 16), (512, 32), (1024, 64)]
+        sweep, chosen = [], None
+        for ef, pd in grid:
+            sp = ph.SearchParameters(ef, ef, pd)
+            cal_run.launch(sp)
+            cal_run.launch(sp)
+            torch.cuda.synchronize()
+            ms = index.kernel_ms()
+            rec = recall_at_10(cal_run.result_ids(ef), cal_gt)
+            qps = cal.n / ms * 1e3
+            sweep.append({"ef": ef, "probe_depth": pd, "recall_at_10": round(rec, 4), "qps_cal": round(qps)})
+            log("sweep ef=%d pd=%d recall@10=%.4f  %.0f q/s" % (ef, pd, rec, qps))
+            if rec >= args.target_recall and (chosen is None or qps > chosen[2]):
+                chosen = (ef, pd, qps, rec)
+        met = chosen is not None
+        if not met:  # report honestly at the BASELINE configuration ef_search=128
+            e = [s for s in sweep if s["ef"] == 128 and s["probe_depth"] == 2] or sweep[:1]
+            chosen = (e[0]["ef"], e[0]["probe_depth"], e[0]["qps_cal"], e[0]["recall_at_10"])
+        ef, pd = chosen[0], chosen[1]
+        sp = ph.SearchParameters(ef, ef, pd)
+        # this rank's own query batch (weak scaling: fixed work per GPU)
+        qstore = make_store(kind, args.nq, 2 ** 32 + rank * args.nq)
+        run = Runner(index, qstore, ef_max=ef)
+        gt = ground_truth(base_t, tensor_of(qstore))
+        for _ in range(args.warmup):
+            run.launch(sp)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.launch(sp)
+            if headline:
+                pass
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # per-launch kernel time from HIP events on the launch stream (separate, untimed pass so
+        # the event reads do not serialise the timed region)
+        for _ in range(min(args.steps, 10)):
+            run.launch(sp)
+            torch.cuda.synchronize()
+            kms.append(index.kernel_ms())
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rec = recall_at_10(run.result_ids(ef), gt)
+        st = run.stats.to(torch.int64)
+        assert int(run.status.abs().sum()) == 0, "search reported per-query errors"
+        w0 = index._layer(index.layer_count() - 1).neighborhood_size
+        n_dist, n_hops = int(st[:, 0].sum()), int(st[:, 1].sum())
+        row_bytes = store.ld * 4
+        alg_bytes = n_dist * row_bytes + n_hops * w0 * 4 + args.nq * ef * 12
+        k_ms = float(np.mean(kms))
+        out = {
+            "dataset": kind, "ef": ef, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
+            "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
+            "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "sweep": sweep,
+        }
+        return out, store, index, qstore, run, sp, gt
+
+    res, store, index, qstore, run, sp, gt = measure_dataset(args.dataset, True)
+    value = world * args.nq * args.steps / res["elapsed"]
+    achieved = res["alg_bytes"] / (res["kernel_ms"] * 1e-3) / 1e9
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        # reference-algorithm CPU restatement (oracle/, kind "port") on this box's host cores,
+        # same graph, same vectors, a bounded sample of the same query batch
+        import oracle
+        cores = os.cpu_count() or 1
+        t0 = time.time()
+        rows_h = store.read()
+        oix = oracle.Index(rows_h, dim=store.dim, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_SEQ)
+        for l in range(index.layer_count()):
+            L = index._layer(l)
+            oix.push_layer(L.nodes, L.neighbors, L.neighborhood_size)
+        qh = qstore.read()
+        log("cpu baseline: copied store+graph to host in %.1f s, %d cores" % (time.time() - t0, cores))
+        spt = (sp.number_of_candidates, sp.upper_layer_candidate_count, sp.probe_depth)
+        t0 = time.time()
+        oix.search(queries=qh[:2 * cores], sp=spt, threads=cores)
+        per_q = (time.time() - t0) / (2 * cores)
+        sample = int(max(2 * cores, min(args.nq, args.cpu_seconds / max(per_q, 1e-9))))
+        t0 = time.time()
+        ci, cd, cl = oix.search(queries=qh[:sample], sp=spt, threads=cores)
+        dt = time.time() - t0
+        crec = recall_at_10(torch.from_numpy(ci[:, :10].astype(np.int64)).to(dev), gt[:sample])
+        gi = run.result_ids(sp.number_of_candidates)[:sample].cpu().numpy().astype(np.uint64)
+        same = float((gi[:, :10] == ci[:, :10]).mean())
+        cpu = {"value": round(sample / dt, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+               "sample": "%d of the %d timed queries, same graph and parameters, sequential-f32 reference arithmetic"
+                         % (sample, args.nq),
+               "recall_at_10": round(crec, 4), "top10_ids_equal_to_gpu": round(same, 5)}
+        log("cpu baseline %.0f q/s on %d cores (%d queries in %.1f s)" % (sample / dt, cores, sample, dt))
+        del oix, rows_h
+
+    iid = None
+    if rank == 0 and world == 1 and not args.no_iid and args.dataset != "iid" and not args.ef:
+        # the reference's own data distribution (bigvec.rs:59-65) at the BASELINE setting ef=128
+        del run, gt, qstore, index, store
+        torch.cuda.empty_cache()
+        saved = (args.ef, args.probe_depth)
+        args.ef, args.probe_depth = 128, 2
+        r2, *_ = measure_dataset("iid", False)
+        args.ef, args.probe_depth = saved
+        iid = {"dataset": "iid-uniform (bigvec.rs:59-65)", "ef": 128, "probe_depth": 2,
+               "queries_per_s": round(args.nq * args.steps / r2["elapsed"]),
+               "recall_at_10": r2["recall_at_10"],
+               "roofline_gbs": round(r2["alg_bytes"] / (r2["kernel_ms"] * 1e-3) / 1e9, 1),
+               "build_vectors_per_s": round(args.n / r2["build_s"])}
+
+    if rank == 0:
+        line = {
+            "metric": "queries/sec at recall@10>=0.95 on 1Mx768 f32",
+            "value": round(value, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: %dx%d f32 cosine (1-dot)/2, batched greedy search, %d queries/step/GPU"
+                            % (args.n, args.dim, args.nq),
+                "dataset": "%s synthetic (1000 unit centres + uniform noise, normalised)" % res["dataset"]
+                           if res["dataset"] == "clustered" else "iid uniform(-1,1) normalised (bigvec.rs:59-65)",
+                "number_of_candidates": res["ef"], "upper_layer_candidate_count": res["ef"],
+                "probe_depth": res["probe_depth"],
+                "build": "reference defaults order=12 M=24 M0=48 ef_link=300 (parameters.rs:50-64), built on GPU",
+                "parallelism": "replicated index, queries sharded x%d" % world,
+            },
+            "recall_at_10": res["recall_at_10"],
+            "recall_target_met": res["recall_target_met"],
+            "build_vectors_per_sec": round(args.n / res["build_s"], 1),
+            "distance_evals_per_query": round(res["n_dist_per_query"], 1),
+            "hops_per_query": round(res["n_hops_per_query"], 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ph_search_kernel", "kernel_ms": round(res["kernel_ms"], 4),
+                         "algorithmic_bytes_per_launch": res["alg_bytes"]},
+            "cpu_baseline": cpu,
+            "secondary": iid,
+            "sweep": res["sweep"],
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

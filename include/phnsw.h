@@ -104,6 +104,11 @@ int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, u
  * generated on the device: component j of vector i keyed (seed + first + i, j) */
 int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
                                  int normalize, int metric, int device, phnsw_store **out);
+/* clustered synthetic rows (n_clusters unit centres + uniform noise of norm ~noise,
+ * normalised): the benchmark dataset on which recall@10 >= 0.95 is reachable */
+int phnsw_store_create_clustered(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
+                                 uint32_t n_clusters, float noise, int metric, int device,
+                                 phnsw_store **out);
 int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim, uint32_t *ld, int *metric,
                      const float **rows_dev);
 /* copy rows [first, first+count) back to the host, dim floats each */

@@ -123,6 +123,7 @@ def lib():
         L.orc_mix64.argtypes = [u64]
         L.orc_shuffle_u64.argtypes = [vp, u64, u64]
         L.orc_synth_rows.argtypes = [vp, u64, u64, u32, u32, u64, i32, i32]
+        L.orc_synth_clustered_rows.argtypes = [vp, u64, u64, u32, u32, u64, u32, f32, i32]
         L.orc_feistel_perm.restype = u64
         L.orc_feistel_perm.argtypes = [u64, u64, u64]
         _lib = L
@@ -207,6 +208,13 @@ def synth_rows(first, count, dim, seed=42, normalize=True, threads=8):
     ld = (dim + 3) // 4 * 4
     rows = np.zeros((count, ld), dtype=np.float32)
     lib().orc_synth_rows(_p(rows), first, count, dim, ld, seed, int(normalize), threads)
+    return rows
+
+
+def synth_clustered_rows(first, count, dim, seed=42, n_clusters=1000, noise=1.0, threads=8):
+    ld = (dim + 3) // 4 * 4
+    rows = np.zeros((count, ld), dtype=np.float32)
+    lib().orc_synth_clustered_rows(_p(rows), first, count, dim, ld, seed, n_clusters, noise, threads)
     return rows
 
 

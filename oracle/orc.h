@@ -176,6 +176,8 @@ void orc_shuffle_u64(uint64_t *v, uint64_t n, uint64_t seed);
  * (seed+i, j), L2-normalised in f32 when normalize != 0 */
 void orc_synth_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                     uint64_t seed, int normalize, int threads);
+void orc_synth_clustered_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
+                              uint64_t seed, uint32_t n_clusters, float noise, int threads);
 /* format-preserving permutation of [0,domain) used by the neighbour seeding step */
 uint64_t orc_feistel_perm(uint64_t i, uint64_t domain, uint64_t key);
 

@@ -129,6 +129,35 @@ void orc_synth_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, u
   }
 }
 
+/* Clustered synthetic rows (SURVEY section 8d's second dataset): n_clusters unit centres
+ * (synthetic normalised rows keyed seed ^ CENTRE_SALT), point i belongs to cluster
+ * mulhi(mix64(..i..), n_clusters) and is normalise(centre + a * u), u_j uniform(-1,1) keyed
+ * (seed + i, j), a = noise * sqrt(3/dim) so that |a*u| ~ noise.  Not in the reference. */
+#define ORC_CENTRE_SALT 0xC1A55E5EEDULL
+void orc_synth_clustered_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
+                              uint64_t seed, uint32_t n_clusters, float noise, int threads) {
+  float *cent = (float *)malloc(sizeof(float) * (size_t)n_clusters * ld);
+  orc_synth_rows(cent, 0, n_clusters, dim, ld, seed ^ ORC_CENTRE_SALT, 1, threads);
+  float a = noise * sqrtf(3.0f / (float)dim);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (uint64_t r = 0; r < count; r++) {
+    float *row = rows + r * (uint64_t)ld;
+    uint64_t key = seed + first + r;
+    uint64_t k = bounded(orc_mix64(key * 0xA24BAED4963EE407ULL + 0x9FB21C651E98DF25ULL), n_clusters);
+    const float *c = cent + k * (uint64_t)ld;
+    float ss = 0.0f;
+    for (uint32_t j = 0; j < dim; j++) {
+      float x = c[j] + a * synth_component(key, j);
+      row[j] = x;
+      ss += x * x;
+    }
+    float norm = sqrtf(ss);
+    for (uint32_t j = 0; j < dim; j++) row[j] = row[j] / norm;
+    for (uint32_t j = dim; j < ld; j++) row[j] = 0.0f;
+  }
+  free(cent);
+}
+
 /* 4-round Feistel network over 2*h bits with cycle walking: a keyed permutation of
  * [0,domain).  Stands in for choose_n_1's shuffle+truncate (src/lib.rs:1830-1852):
  * the first k images are a pseudo-random k-subset. */

@@ -51,6 +51,7 @@ SYMBOLS = {
     "phnsw_store_create": (_i32, [_vp, _u64, _u32, _i32, _i32, _pp]),
     "phnsw_store_create_device": (_i32, [_vp, _u64, _u32, _u32, _i32, _i32, _pp]),
     "phnsw_store_create_synthetic": (_i32, [_u64, _u64, _u32, _u64, _i32, _i32, _i32, _pp]),
+    "phnsw_store_create_clustered": (_i32, [_u64, _u64, _u32, _u64, _u32, _f32, _i32, _i32, _pp]),
     "phnsw_store_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_i32), _pp]),
     "phnsw_store_read": (_i32, [_vp, _u64, _u64, _vp]),
     "phnsw_store_destroy": (None, [_vp]),

@@ -194,6 +194,36 @@ extern "C" int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t
   return 0;
 }
 
+extern "C" int phnsw_store_create_clustered(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
+                                            uint32_t n_clusters, float noise, int metric, int device,
+                                            phnsw_store **out) {
+  if (!out || dim == 0 || n == 0 || n_clusters == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
+    ph_set_error("phnsw_store_create_clustered: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  int rc = use_device(device);
+  if (rc) return rc;
+  phnsw_store *s = new phnsw_store();
+  s->device = device;
+  s->n = n;
+  s->dim = dim;
+  s->ld = (dim + 3) / 4 * 4;
+  s->metric = metric;
+  hipError_t e = hipMalloc(&s->rows, (size_t)n * s->ld * 4);
+  if (e != hipSuccess) {
+    delete s;
+    return ph_hip_fail(e, "hipMalloc store", __FILE__, __LINE__);
+  }
+  rc = ph_synth_clustered_rows(s->rows, first, n, dim, s->ld, seed, n_clusters, noise, 0);
+  if (rc) {
+    hipFree(s->rows);
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
 extern "C" int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim, uint32_t *ld, int *metric,
                                 const float **rows_dev) {
   if (!s) return PHNSW_E_INVALID;

@@ -92,6 +92,47 @@ int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim,
   return 0;
 }
 
+// clustered variant (SURVEY section 8d second dataset; definition shared with the oracle)
+__global__ void ph_synth_clustered_kernel(float *rows, const float *cent, uint64_t first, uint64_t count, uint32_t dim,
+                                          uint32_t ld, uint64_t seed, uint32_t n_clusters, float a) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  float *row = rows + r * (uint64_t)ld;
+  uint64_t key = seed + first + r;
+  uint64_t k = ph_mulhi64(ph_mix64(key * 0xA24BAED4963EE407ULL + 0x9FB21C651E98DF25ULL), n_clusters);
+  const float *c = cent + k * (uint64_t)ld;
+  float ss = 0.0f;
+  for (uint32_t j = 0; j < dim; j++) {
+    float x = __fadd_rn(c[j], __fmul_rn(a, ph_synth_component(key, j)));
+    ss = __fadd_rn(ss, __fmul_rn(x, x));
+  }
+  float norm = sqrtf(ss);
+  for (uint32_t j = 0; j < dim; j++) {
+    float x = __fadd_rn(c[j], __fmul_rn(a, ph_synth_component(key, j)));
+    row[j] = __fdiv_rn(x, norm);
+  }
+  for (uint32_t j = dim; j < ld; j++) row[j] = 0.0f;
+}
+
+int ph_synth_clustered_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld, uint64_t seed,
+                            uint32_t n_clusters, float noise, hipStream_t s) {
+  if (count == 0) return 0;
+  float *cent = nullptr;
+  PH_HIP(hipMalloc(&cent, (size_t)n_clusters * ld * 4));
+  int rc = ph_synth_rows(cent, 0, n_clusters, dim, ld, seed ^ 0xC1A55E5EEDULL, 1, s);
+  if (!rc) {
+    float a = noise * sqrtf(3.0f / (float)dim);
+    uint32_t blocks = (uint32_t)((count + 63) / 64);
+    hipLaunchKernelGGL(ph_synth_clustered_kernel, dim3(blocks), dim3(64), 0, s, rows_dev, cent, first, count, dim, ld,
+                       seed, n_clusters, a);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "clustered synth", __FILE__, __LINE__);
+  }
+  hipFree(cent);
+  return rc;
+}
+
 __global__ void ph_fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     p[i] = v;

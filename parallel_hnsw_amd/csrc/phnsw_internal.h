@@ -121,6 +121,8 @@ uint32_t ph_search_slots(uint32_t ef, uint32_t nv4);
 // misc kernels (misc.hip)
 int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                   uint64_t seed, int normalize, hipStream_t s);
+int ph_synth_clustered_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld, uint64_t seed,
+                            uint32_t n_clusters, float noise, hipStream_t s);
 int ph_distance_batch(const phnsw_store *st, const float *q_dev, const uint32_t *ids_dev, uint32_t k,
                       float *out_dev, hipStream_t s);
 int ph_fill_u32(uint32_t *p, uint32_t v, uint64_t n, hipStream_t s);

@@ -80,6 +80,13 @@ class VectorStore:
         return cls(_handle=h, device=device)
 
     @classmethod
+    def clustered(cls, n, dim, seed=42, first=0, n_clusters=1000, noise=1.0, metric=METRIC_COSINE_HALF, device=0):
+        """clustered synthetic rows (benchmark dataset)"""
+        h = C.c_void_p()
+        check(lib().phnsw_store_create_clustered(first, n, dim, seed, n_clusters, noise, metric, device, C.byref(h)))
+        return cls(_handle=h, device=device)
+
+    @classmethod
     def from_device(cls, data_ptr, n, dim, ld, metric=METRIC_COSINE_HALF, device=0, keepalive=None):
         h = C.c_void_p()
         check(lib().phnsw_store_create_device(C.c_void_p(data_ptr), n, dim, ld, metric, device, C.byref(h)))
@@ -108,7 +115,10 @@ class VectorStore:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib().phnsw_store_destroy(h)
+            try:
+                lib().phnsw_store_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
 
 
 class Layer:
@@ -245,6 +255,15 @@ class Hnsw:
                                                   _p(ln), _p(st)))
         return (ids, d, ln, st) if stats else (ids, d, ln)
 
+    def search_batch_device(self, nq, sp, out_ids, out_d, out_len, status, queries=0, ldq=0, qids=0, exclude=0,
+                            out_stats=0, upto=0, stream=0):
+        """zero-copy launch: every argument is a device pointer (int); u32 ids; returns after
+        enqueueing on `stream` (a hipStream_t value, 0 = default stream)"""
+        check(lib().phnsw_search_batch_device(self._h, C.c_void_p(queries or None), ldq, C.c_void_p(qids or None), nq,
+                                              C.byref(sp), upto, C.c_void_p(exclude or None), C.c_void_p(out_ids),
+                                              C.c_void_p(out_d), C.c_void_p(out_len), C.c_void_p(out_stats or None),
+                                              C.c_void_p(status), C.c_void_p(stream or None)))
+
     def search(self, v, sp=None):
         """Hnsw::search(v, sp) -> Vec<(VectorId, f32)>  lib.rs:663-665"""
         if isinstance(v, Stored):
@@ -279,4 +298,7 @@ class Hnsw:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib().phnsw_index_destroy(h)
+            try:
+                lib().phnsw_index_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass

@@ -68,6 +68,16 @@ def test_synthetic_store_matches_oracle_generator():
                                   oracle.synth_rows(2 ** 32, 50, 7, seed=9, normalize=False)[:, :7].view(np.uint32))
 
 
+def test_clustered_store_matches_oracle_generator():
+    s = ph.VectorStore.clustered(3000, 96, seed=42, n_clusters=37, noise=1.0)
+    np.testing.assert_array_equal(s.read().view(np.uint32),
+                                  oracle.synth_clustered_rows(0, 3000, 96, n_clusters=37)[:, :96].view(np.uint32))
+    s2 = ph.VectorStore.clustered(64, 10, seed=5, first=2 ** 32, n_clusters=3, noise=0.25)
+    np.testing.assert_array_equal(
+        s2.read().view(np.uint32),
+        oracle.synth_clustered_rows(2 ** 32, 64, 10, seed=5, n_clusters=3, noise=0.25)[:, :10].view(np.uint32))
+
+
 @pytest.mark.parametrize("n,dim,ef,upper,pd", [
     (2000, 128, 64, 64, 2),
     (2000, 128, 128, 16, 2),     # upper_layer_candidate_count < ef: take() + merge path
