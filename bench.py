@@ -123,9 +123,30 @@ def main():
         torch.cuda.synchronize()
         log("%s store %d x %d generated in %.1f s" % (kind, args.n, args.dim, time.time() - t0))
         bp = ph.BuildParameters()
-        t0 = time.time()
-        index = ph.Hnsw.generate(store, np.arange(args.n, dtype=np.uint64), bp)
+        build_mode = "single GPU"
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
+        t0 = time.time()
+        index = None
+        if world > 1:
+            # index construction sharded over the ranks: node ranges per round, RCCL all-gather
+            # of the per-node results (parallel_hnsw_amd/sharded.py)
+            try:
+                eng = ph.GpuEngine(store, bp, device=dev)
+                comm = ph.TorchComm()
+                index = ph.ShardedBuilder(eng, comm).generate(np.arange(args.n, dtype=np.uint64))
+                build_mode = "sharded x%d, %.0f MB all-gathered per rank" % (world, comm.bytes_gathered / 1e6)
+            except Exception as exc:  # keep the search measurement alive; say what happened
+                log("sharded build failed (%r); every rank builds the full index instead" % (exc,))
+                index = None
+        if index is None:
+            if world > 1:
+                build_mode = "replicated (each rank built the full index)"
+            index = ph.Hnsw.generate(store, np.arange(args.n, dtype=np.uint64), bp)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         build_s = time.time() - t0
         log("index built in %.1f s (%.0f vectors/s), layers %s" % (
             build_s, args.n / build_s, [index._layer(l).node_count() for l in range(index.layer_count())]))
@@ -200,13 +221,25 @@ def main():
         out = {
             "dataset": kind, "ef": ef, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
-            "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "sweep": sweep,
+            "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
         }
         return out, store, index, qstore, run, sp, gt
 
     res, store, index, qstore, run, sp, gt = measure_dataset(args.dataset, True)
     value = world * args.nq * args.steps / res["elapsed"]
     achieved = res["alg_bytes"] / (res["kernel_ms"] * 1e-3) / 1e9
+
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this very workload
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "search_kernel_summary.json"))):
+            pm = json.load(open(f)).get("pmc", {})
+            w = pm.get("workload", {})
+            if (w.get("dataset"), w.get("n"), w.get("dim"), w.get("nq"), w.get("ef"), w.get("probe_depth")) == (
+                    res["dataset"], args.n, args.dim, args.nq, res["ef"], res["probe_depth"]):
+                traffic = pm.get("traffic_bytes_per_launch")
+    except Exception:
+        traffic = None
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -282,10 +315,11 @@ def main():
             "recall_at_10": res["recall_at_10"],
             "recall_target_met": res["recall_target_met"],
             "build_vectors_per_sec": round(args.n / res["build_s"], 1),
+            "build_mode": res["build_mode"],
             "distance_evals_per_query": round(res["n_dist_per_query"], 1),
             "hops_per_query": round(res["n_hops_per_query"], 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "ph_search_kernel", "kernel_ms": round(res["kernel_ms"], 4),
                          "algorithmic_bytes_per_launch": res["alg_bytes"]},
             "cpu_baseline": cpu,

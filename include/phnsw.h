@@ -181,6 +181,45 @@ int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, u
  * events on its stream: kernel milliseconds */
 int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
 
+/* ---- phase API: the per-round pieces of phnsw_generate_layer / phnsw_link_layer /
+ * phnsw_stochastic_recall_at over a NODE RANGE, device buffers, u32 ids (0xFFFFFFFF empty).
+ * A multi-GPU driver (parallel_hnsw_amd/sharded.py) gives every rank a replica of store and
+ * graph, lets rank r run the searches of its node range, all-gathers the per-node results
+ * over RCCL and lets every rank apply them -- replicas stay bit-identical.  The
+ * single-GPU entry points above are these phases over the whole range. ---- */
+int phnsw_index_create(phnsw_store *s, const phnsw_build_params *bp, phnsw_index **out); /* no layers yet */
+/* the id shuffle of phnsw_build (lib.rs:832-833) and its layer sizes, top first
+ * (calculate_partitions lib.rs:1883-1899) */
+int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                     uint64_t *shuffled, uint64_t *layer_sizes, uint32_t max_layers,
+                     uint32_t *layer_count);
+/* generate_layer: begin (sort, id maps; *needs_phases = 0 when the layer is already complete:
+ * first layer of a stack) -> init_search(range) -> seed(range) -> finish */
+int phnsw_layer_begin(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
+                      const phnsw_build_params *bp, int *needs_phases);
+/* out_* : [count][K] NodeIds of the new layer / distances, [count] lengths;
+ * K = initial_partition_search.number_of_candidates  (search.rs:32-71) */
+int phnsw_layer_init_search_device(phnsw_index *ix, const phnsw_build_params *bp, uint64_t first,
+                                   uint64_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len);
+/* init_* : the FULL [n][K] lists; out_rows : [count][W]  (lib.rs:711-787) */
+int phnsw_layer_seed_device(phnsw_index *ix, const phnsw_build_params *bp, const uint32_t *init_ids,
+                            const float *init_d, const uint32_t *init_len, uint64_t first,
+                            uint64_t count, uint32_t *out_rows, float *out_rows_d);
+/* rows : the FULL [n][W] seeded rows; bidirectional pass + push  (lib.rs:789-822) */
+int phnsw_layer_finish_device(phnsw_index *ix, const uint32_t *rows, const float *rows_d);
+/* link round: searches of nodes [first, first+count) -> best link_count results as
+ * VectorIds [count][link_count]  (lib.rs:1107-1117) */
+int phnsw_link_search_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                             uint64_t link_count, uint64_t first, uint64_t count, uint32_t *out_ids,
+                             float *out_d, uint32_t *out_len);
+/* ... and the row updates from the FULL [n][link_count] results  (lib.rs:1118-1147) */
+int phnsw_link_apply_device(phnsw_index *ix, uint32_t layer_from_top, uint64_t link_count,
+                            const uint32_t *ids, const float *d, const uint32_t *len,
+                            uint64_t *out_added);
+/* self-hits among sample[first, first+count) of stochastic_recall_at; *out_selection = sample size */
+int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
+                      uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection);
+
 /* Hnsw::knn  src/lib.rs:905-928 : bottom layer, out [node_count][k] */
 int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
               float *out_d, uint64_t *out_len);

@@ -109,6 +109,22 @@ def lib():
         L.orc_generate.argtypes = [vp, u64, u32, u32, i32, i32, vp, u64, C.POINTER(BuildParams), i32]
         L.orc_generate_layer.restype = i32
         L.orc_generate_layer.argtypes = [vp, vp, u64, u64, C.POINTER(BuildParams), i32]
+        L.orc_layer_begin.restype = i32
+        L.orc_layer_begin.argtypes = [vp, vp, u64, u64, C.POINTER(BuildParams)]
+        L.orc_layer_init_stride.restype = u64
+        L.orc_layer_init_stride.argtypes = [vp]
+        L.orc_layer_init_search.restype = i32
+        L.orc_layer_init_search.argtypes = [vp, C.POINTER(BuildParams), u64, u64, vp, vp, vp, i32]
+        L.orc_layer_seed.restype = i32
+        L.orc_layer_seed.argtypes = [vp, C.POINTER(BuildParams), vp, vp, vp, u64, u64, vp, vp, i32]
+        L.orc_layer_finish.restype = i32
+        L.orc_layer_finish.argtypes = [vp, vp, vp, i32]
+        L.orc_link_search.restype = i32
+        L.orc_link_search.argtypes = [vp, u32, SearchParams, u64, u64, u64, vp, vp, vp, i32]
+        L.orc_link_apply.restype = u64
+        L.orc_link_apply.argtypes = [vp, u32, u64, vp, vp, vp, i32]
+        L.orc_recall_hits.restype = i32
+        L.orc_recall_hits.argtypes = [vp, u32, C.POINTER(OptParams), u64, u64, C.POINTER(u64), C.POINTER(u64), i32]
         L.orc_link_layer.restype = u64
         L.orc_link_layer.argtypes = [vp, u32, SearchParams, u64, i32]
         L.orc_stochastic_recall_at.restype = f32

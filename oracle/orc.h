@@ -155,6 +155,23 @@ orc_index *orc_generate(const float *rows, uint64_t n_store, uint32_t dim, uint3
 /* generate_layer lib.rs:675-823 appended to ix (no improve) */
 int orc_generate_layer(orc_index *ix, const uint64_t *vs, uint64_t n, uint64_t neighborhood_size,
                        const orc_build_params *bp, int threads);
+/* the same in phases over node ranges (what a multi-GPU driver shards; see orc_build.c) */
+int orc_layer_begin(orc_index *ix, const uint64_t *vs, uint64_t n, uint64_t neighborhood_size,
+                    const orc_build_params *bp);
+uint64_t orc_layer_init_stride(const orc_index *ix);
+int orc_layer_init_search(orc_index *ix, const orc_build_params *bp, uint64_t first, uint64_t count,
+                          uint64_t *out_ids, float *out_d, uint64_t *out_len, int threads);
+int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *init_ids, const float *init_d,
+                   const uint64_t *init_len, uint64_t first, uint64_t count, uint64_t *out_rows,
+                   float *out_rows_d, int threads);
+int orc_layer_finish(orc_index *ix, const uint64_t *rows, const float *rows_d, int threads);
+int orc_link_search(orc_index *ix, uint32_t layer_from_top, orc_search_params sp, uint64_t link_count,
+                    uint64_t first, uint64_t count, uint64_t *out_ids, float *out_d, uint64_t *out_len,
+                    int threads);
+uint64_t orc_link_apply(orc_index *ix, uint32_t layer_from_top, uint64_t link_count, const uint64_t *ids,
+                        const float *d, const uint64_t *len, int threads);
+int orc_recall_hits(const orc_index *ix, uint32_t at, const orc_opt_params *op, uint64_t first, uint64_t count,
+                    uint64_t *out_hits, uint64_t *out_selection, int threads);
 /* link_layer_to_better_neighbors lib.rs:1070-1154 ; returns new edges */
 uint64_t orc_link_layer(orc_index *ix, uint32_t layer_from_top, orc_search_params sp,
                         uint64_t link_count, int threads);

@@ -197,46 +197,66 @@ static int gm_cmp(const void *a, const void *b) {
 
 /* ---------------------------------------------------------------- generate_layer */
 
-/* Hnsw::generate_layer  src/lib.rs:675-823 (new_top = false) */
-int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_t W,
-                       const orc_build_params *bp, int threads) {
+/* generate_layer runs in four phases (begin / init_search(range) / seed(range) / finish) so
+ * that tests can drive the same node-range sharding the multi-GPU build uses; the
+ * monolithic orc_generate_layer below is the phases over the whole range. */
+
+static void pending_free(orc_index *ix) {
+  free(ix->p_vs);
+  free(ix->p_gm);
+  free(ix->p_gstart);
+  free(ix->p_gsize);
+  ix->p_vs = NULL;
+  ix->p_gm = NULL;
+  ix->p_gstart = ix->p_gsize = NULL;
+  ix->p_n = 0;
+  ix->p_grouped = 0;
+}
+void orc_pending_free(orc_index *ix) { pending_free(ix); }
+
+/* vs.sort(), allocate  src/lib.rs:683-693 */
+int orc_layer_begin(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_t W, const orc_build_params *bp) {
   if (n == 0 || W == 0) return -3; /* assert!(!vs.is_empty()) :683 */
+  pending_free(ix);
+  ix->p_vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  memcpy(ix->p_vs, vs_in, sizeof(uint64_t) * n);
+  qsort(ix->p_vs, n, sizeof(uint64_t), u64_cmp); /* vs.sort() :685 */
+  ix->p_n = n;
+  ix->p_W = W;
+  ix->p_K = ix->layer_count == 0 ? (n > 1 ? n - 1 : 1) : bp->initial_partition_search.number_of_candidates;
+  return 0;
+}
+uint64_t orc_layer_init_stride(const orc_index *ix) { return ix->p_K; }
+
+/* 1. generate_initial_partitions for nodes [first, first+count)  src/search.rs:32-71;
+ * out_ids/out_d are [count][K], out_len [count] */
+int orc_layer_init_search(orc_index *ix, const orc_build_params *bp, uint64_t first, uint64_t count,
+                          uint64_t *out_ids, float *out_d, uint64_t *out_len, int threads) {
   const orc_store *S = &ix->store;
-  int T = threads > 0 ? threads : 1;
-  uint64_t *vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
-  memcpy(vs, vs_in, sizeof(uint64_t) * n);
-  qsort(vs, n, sizeof(uint64_t), u64_cmp); /* vs.sort() :685 */
-  uint64_t *rows = (uint64_t *)malloc(sizeof(uint64_t) * n * W);
-  float *rows_d = (float *)malloc(sizeof(float) * n * W);
-  for (uint64_t i = 0; i < n * W; i++) {
-    rows[i] = ORC_EMPTY;
-    rows_d[i] = ORC_FMAX;
-  }
+  const uint64_t *vs = ix->p_vs;
+  uint64_t n = ix->p_n, K = ix->p_K;
+  if (!vs || first + count > n) return -3;
   uint32_t layer_count = ix->layer_count;
   orc_search_params ips = bp->initial_partition_search;
-
-  /* 1. generate_initial_partitions  src/search.rs:32-71 */
-  uint64_t K = layer_count == 0 ? (n > 1 ? n - 1 : 1) : ips.number_of_candidates;
-  nd_pair *init = (nd_pair *)malloc(sizeof(nd_pair) * n * K);
-  uint64_t *init_len = (uint64_t *)calloc(n, sizeof(uint64_t));
   int rc_all = 0;
-#pragma omp parallel num_threads(T)
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_scratch *sc = layer_count ? orc_scratch_new(ix, 0) : NULL;
     uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * (ips.number_of_candidates + 1));
     float *od = (float *)malloc(sizeof(float) * (ips.number_of_candidates + 1));
+    nd_pair *tmp = (nd_pair *)malloc(sizeof(nd_pair) * (K + 1));
 #pragma omp for schedule(dynamic, 16)
-    for (uint64_t i = 0; i < n; i++) {
-      nd_pair *L = init + i * K;
+    for (uint64_t x = 0; x < count; x++) {
+      uint64_t i = first + x;
       uint64_t m = 0;
       if (layer_count == 0) {
         /* compare_all  src/search.rs:13-30 */
         for (uint64_t j = 0; j < n; j++) {
           if (vs[j] == vs[i]) continue;
           nd_pair p = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[j] * (uint64_t)S->ld), j};
-          L[m++] = p;
+          tmp[m++] = p;
         }
-        qsort(L, m, sizeof(nd_pair), nd_cmp); /* ids are node ids; monotone in vector id */
+        qsort(tmp, m, sizeof(nd_pair), nd_cmp); /* ids are node ids; monotone in vector id */
       } else {
         /* initial_vector_distances  src/search.rs:73-82 */
         uint64_t len = 0;
@@ -256,57 +276,86 @@ int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_
             continue;
           }
           nd_pair p = {od[k], (uint64_t)(hit - vs)};
-          L[m++] = p;
+          tmp[m++] = p;
         }
       }
-      init_len[i] = m;
+      for (uint64_t k = 0; k < m; k++) {
+        out_ids[x * K + k] = tmp[k].id;
+        out_d[x * K + k] = tmp[k].d;
+      }
+      for (uint64_t k = m; k < K; k++) {
+        out_ids[x * K + k] = ORC_EMPTY;
+        out_d[x * K + k] = ORC_FMAX;
+      }
+      out_len[x] = m;
     }
     free(oi);
     free(od);
+    free(tmp);
     orc_scratch_free(sc);
   }
-  if (rc_all) {
-    free(vs); free(rows); free(rows_d); free(init); free(init_len);
-    return rc_all;
-  }
+  return rc_all;
+}
 
-  /* 2. partition groups keyed by the nearest super node (src/lib.rs:711-713).  Member
-   * order = the sort of src/search.rs:67-69 (first distance; None first), made total with
-   * the node id. */
+/* 2. partition groups keyed by the nearest super node (src/lib.rs:711-713) from the FULL
+ * init lists.  Member order = the sort of src/search.rs:67-69 (first distance; None
+ * first), made total with the node id. */
+static void layer_group(orc_index *ix, const uint64_t *init_ids, const float *init_d, const uint64_t *init_len) {
+  uint64_t n = ix->p_n, K = ix->p_K;
   gm_t *gm = (gm_t *)malloc(sizeof(gm_t) * n);
   for (uint64_t i = 0; i < n; i++) {
     gm[i].node = i;
     if (init_len[i]) {
-      gm[i].key = init[i * K].id;
-      gm[i].d = init[i * K].d;
+      gm[i].key = init_ids[i * K];
+      gm[i].d = init_d[i * K];
     } else {
       gm[i].key = ORC_EMPTY;
       gm[i].d = 0.0f;
     }
   }
   qsort(gm, n, sizeof(gm_t), gm_cmp);
-  uint64_t *gstart = (uint64_t *)calloc(n + 1, sizeof(uint64_t)); /* per key node; slot n = None */
-  uint64_t *gsize = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
+  ix->p_gm = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  ix->p_gstart = (uint64_t *)calloc(n + 1, sizeof(uint64_t)); /* per key node; slot n = None */
+  ix->p_gsize = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
   for (uint64_t p = 0; p < n; p++) {
+    ix->p_gm[p] = gm[p].node;
     uint64_t slot = gm[p].key == ORC_EMPTY ? n : gm[p].key;
-    if (gsize[slot] == 0) gstart[slot] = p;
-    gsize[slot]++;
+    if (ix->p_gsize[slot] == 0) ix->p_gstart[slot] = p;
+    ix->p_gsize[slot]++;
   }
+  free(gm);
+  ix->p_grouped = 1;
+}
 
-  /* 3. neighbourhood seeding  src/lib.rs:719-787 */
-#pragma omp parallel num_threads(T)
+/* 3. neighbourhood seeding for nodes [first, first+count)  src/lib.rs:719-787;
+ * out_rows/out_rows_d are [count][W] */
+int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *init_ids, const float *init_d,
+                   const uint64_t *init_len, uint64_t first, uint64_t count, uint64_t *out_rows, float *out_rows_d,
+                   int threads) {
+  const orc_store *S = &ix->store;
+  const uint64_t *vs = ix->p_vs;
+  uint64_t n = ix->p_n, K = ix->p_K, W = ix->p_W;
+  if (!vs || first + count > n) return -3;
+  if (!ix->p_grouped) layer_group(ix, init_ids, init_d, init_len);
+  const uint64_t *gmem = ix->p_gm, *gstart = ix->p_gstart, *gsize = ix->p_gsize;
+  uint32_t layer_count = ix->layer_count;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     uint64_t maxc = W * 5 + K + 8;
     nd_pair *list = (nd_pair *)malloc(sizeof(nd_pair) * maxc);
     uint64_t *pstart = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
     uint64_t *psize = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
 #pragma omp for schedule(dynamic, 16)
-    for (uint64_t i = 0; i < n; i++) {
+    for (uint64_t x = 0; x < count; x++) {
+      uint64_t i = first + x;
       uint64_t m = 0;
-      for (uint64_t k = 0; k < init_len[i]; k++) list[m++] = init[i * K + k]; /* distances.clone() */
+      for (uint64_t k = 0; k < init_len[i]; k++) { /* distances.clone() */
+        nd_pair p = {init_d[i * K + k], init_ids[i * K + k]};
+        list[m++] = p;
+      }
       uint64_t np = 0, total = 0;
       for (uint64_t k = 0; k < init_len[i]; k++) { /* filter_map(partition_groups.get(Some(n))) */
-        uint64_t s = init[i * K + k].id;
+        uint64_t s = init_ids[i * K + k];
         if (gsize[s]) {
           pstart[np] = gstart[s];
           psize[np] = gsize[s];
@@ -315,7 +364,7 @@ int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_
         }
       }
       if (np == 0) { /* partitions.push(partition) : our own group  :739-742 */
-        uint64_t slot = init_len[i] ? init[i * K].id : n;
+        uint64_t slot = init_len[i] ? init_ids[i * K] : n;
         pstart[0] = gstart[slot];
         psize[0] = gsize[slot];
         total = gsize[slot];
@@ -338,19 +387,28 @@ int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_
           f -= psize[p];
           p++;
         }
-        uint64_t member = gm[pstart[p] + f].node;
+        uint64_t member = gmem[pstart[p] + f];
         /* compare_vec(Stored(vector_id), Stored(choice.1))  :750-754 */
         nd_pair c = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[member] * (uint64_t)S->ld), member};
         list[m++] = c;
       }
-      finish_row(list, m, i, W, rows + i * W, rows_d + i * W);
+      finish_row(list, m, i, W, out_rows + x * W, out_rows_d + x * W);
     }
     free(list);
     free(pstart);
     free(psize);
   }
+  return 0;
+}
 
-  /* 4. make neighbourhoods bidirectional  src/lib.rs:789-815 (snapshot form) */
+/* 4. make neighbourhoods bidirectional  src/lib.rs:789-815 (snapshot form) + push */
+int orc_layer_finish(orc_index *ix, const uint64_t *rows_in, const float *rows_d_in, int threads) {
+  uint64_t n = ix->p_n, W = ix->p_W;
+  if (!ix->p_vs) return -3;
+  uint64_t *rows = (uint64_t *)malloc(sizeof(uint64_t) * n * W);
+  float *rows_d = (float *)malloc(sizeof(float) * n * W);
+  memcpy(rows, rows_in, sizeof(uint64_t) * n * W);
+  memcpy(rows_d, rows_d_in, sizeof(float) * n * W);
   uint64_t np = 0;
   for (uint64_t i = 0; i < n * W; i++)
     if (rows[i] != ORC_EMPTY) np++;
@@ -366,54 +424,73 @@ int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_
         pd[c] = rows_d[i * W + k];
         c++;
       }
-  merge_proposals(n, W, rows, rows_d, pt, ps, pd, np, T);
+  merge_proposals(n, W, rows, rows_d, pt, ps, pd, np, threads > 0 ? threads : 1);
   free(pt); free(ps); free(pd);
-
-  orc_index_push_layer(ix, vs, rows, n, W);
-  free(gm); free(gstart); free(gsize); free(init); free(init_len);
-  free(vs); free(rows); free(rows_d);
+  orc_index_push_layer(ix, ix->p_vs, rows, n, W);
+  free(rows); free(rows_d);
+  pending_free(ix);
   return 0;
+}
+
+/* Hnsw::generate_layer  src/lib.rs:675-823 (new_top = false) */
+int orc_generate_layer(orc_index *ix, const uint64_t *vs_in, uint64_t n, uint64_t W,
+                       const orc_build_params *bp, int threads) {
+  int rc = orc_layer_begin(ix, vs_in, n, W, bp);
+  if (rc) return rc;
+  uint64_t K = ix->p_K;
+  uint64_t *init_ids = (uint64_t *)malloc(sizeof(uint64_t) * n * K);
+  float *init_d = (float *)malloc(sizeof(float) * n * K);
+  uint64_t *init_len = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  uint64_t *rows = (uint64_t *)malloc(sizeof(uint64_t) * n * W);
+  float *rows_d = (float *)malloc(sizeof(float) * n * W);
+  rc = orc_layer_init_search(ix, bp, 0, n, init_ids, init_d, init_len, threads);
+  if (!rc) rc = orc_layer_seed(ix, bp, init_ids, init_d, init_len, 0, n, rows, rows_d, threads);
+  if (!rc) rc = orc_layer_finish(ix, rows, rows_d, threads);
+  if (rc) pending_free(ix);
+  free(init_ids); free(init_d); free(init_len); free(rows); free(rows_d);
+  return rc;
 }
 
 /* ---------------------------------------------------------------- link round */
 
-/* link_nodes_in_layer_to_better_neighbors over all nodes  src/lib.rs:1070-1154.
- * link_count = self.neighborhood_size() (bp.neighborhood_size, also on layer 0: :1093) */
-uint64_t orc_link_layer(orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t link_count,
-                        int threads) {
-  const orc_store *S = &ix->store;
+/* link round phase 1: searches of nodes [first, first+count) against the unmodified layer
+ * (pseudo_layer = clone :1097-1100); out_ids [count][link_count] VectorIds */
+int orc_link_search(orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t link_count, uint64_t first,
+                    uint64_t count, uint64_t *out_ids, float *out_d, uint64_t *out_len, int threads) {
   orc_layer *L = &ix->layers[lft];
-  uint64_t n = L->node_count, W = L->neighborhood_size;
-  int T = threads > 0 ? threads : 1;
-  uint64_t *pt = (uint64_t *)malloc(sizeof(uint64_t) * n * link_count);
-  float *pd = (float *)malloc(sizeof(float) * n * link_count);
-  uint64_t *pcount = (uint64_t *)calloc(n, sizeof(uint64_t));
-  /* searches run against the unmodified layer (pseudo_layer = clone :1097-1100) */
-#pragma omp parallel num_threads(T)
+  if (first + count > L->node_count) return -3;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_scratch *sc = orc_scratch_new(ix, 0);
     uint64_t cap = sp.number_of_candidates;
     uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
     float *od = (float *)malloc(sizeof(float) * cap);
 #pragma omp for schedule(dynamic, 16)
-    for (uint64_t i = 0; i < n; i++) {
-      uint64_t vector = L->nodes[i];
+    for (uint64_t x = 0; x < count; x++) {
+      uint64_t vector = L->nodes[first + x];
       uint64_t len = 0;
       /* search_layers(Stored(vector), sp, &pseudo_stack, Some(vector))  :1112-1117 */
       orc_search_sc(ix, NULL, vector, sp, lft + 1, vector, oi, od, &len, NULL, sc, NULL);
-      uint64_t m = 0;
-      for (uint64_t k = 0; k < len && k < link_count; k++) { /* take(neighborhood_size) */
-        if (oi[k] == vector) break;                           /* :1119-1121 */
-        pt[i * link_count + m] = orc_layer_get_node(L, oi[k]);
-        pd[i * link_count + m] = od[k];
-        m++;
+      for (uint64_t k = 0; k < link_count; k++) {
+        out_ids[x * link_count + k] = k < len ? oi[k] : ORC_EMPTY;
+        out_d[x * link_count + k] = k < len ? od[k] : ORC_FMAX;
       }
-      pcount[i] = m;
+      out_len[x] = len;
     }
     free(oi);
     free(od);
     orc_scratch_free(sc);
   }
+  return 0;
+}
+
+/* link round phase 2: proposals -> rows  :1118-1147 */
+uint64_t orc_link_apply(orc_index *ix, uint32_t lft, uint64_t link_count, const uint64_t *res_ids,
+                        const float *res_d, const uint64_t *res_len, int threads) {
+  const orc_store *S = &ix->store;
+  orc_layer *L = &ix->layers[lft];
+  uint64_t n = L->node_count, W = L->neighborhood_size;
+  int T = threads > 0 ? threads : 1;
   /* distances of the current occupants to the row owner, recomputed as :1128-1133 does */
   float *rows_d = (float *)malloc(sizeof(float) * n * W);
 #pragma omp parallel for num_threads(T) schedule(dynamic, 64)
@@ -424,28 +501,45 @@ uint64_t orc_link_layer(orc_index *ix, uint32_t lft, orc_search_params sp, uint6
                                          : orc_distance(S, S->rows + L->nodes[o] * (uint64_t)S->ld,
                                                         S->rows + L->nodes[t] * (uint64_t)S->ld);
     }
-  uint64_t np = 0;
-  for (uint64_t i = 0; i < n; i++) np += pcount[i];
-  uint64_t *ft = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
-  uint64_t *fs = (uint64_t *)malloc(sizeof(uint64_t) * (np ? np : 1));
-  float *fd = (float *)malloc(sizeof(float) * (np ? np : 1));
+  uint64_t *ft = (uint64_t *)malloc(sizeof(uint64_t) * (n * link_count + 1));
+  uint64_t *fs = (uint64_t *)malloc(sizeof(uint64_t) * (n * link_count + 1));
+  float *fd = (float *)malloc(sizeof(float) * (n * link_count + 1));
   uint64_t c = 0;
-  for (uint64_t i = 0; i < n; i++)
-    for (uint64_t k = 0; k < pcount[i]; k++) {
-      ft[c] = pt[i * link_count + k];
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t vector = L->nodes[i];
+    for (uint64_t k = 0; k < res_len[i] && k < link_count; k++) { /* take(neighborhood_size) */
+      uint64_t w = res_ids[i * link_count + k];
+      if (w == vector) break; /* :1119-1121 */
+      ft[c] = orc_layer_get_node(L, w);
       fs[c] = i;
-      fd[c] = pd[i * link_count + k];
+      fd[c] = res_d[i * link_count + k];
       c++;
     }
-  uint64_t added = merge_proposals(n, W, L->neighbors, rows_d, ft, fs, fd, np, T);
-  free(ft); free(fs); free(fd); free(rows_d); free(pt); free(pd); free(pcount);
+  }
+  uint64_t added = merge_proposals(n, W, L->neighbors, rows_d, ft, fs, fd, c, T);
+  free(ft); free(fs); free(fd); free(rows_d);
+  return added;
+}
+
+/* link_nodes_in_layer_to_better_neighbors over all nodes  src/lib.rs:1070-1154.
+ * link_count = self.neighborhood_size() (bp.neighborhood_size, also on layer 0: :1093) */
+uint64_t orc_link_layer(orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t link_count,
+                        int threads) {
+  uint64_t n = ix->layers[lft].node_count;
+  uint64_t *ids = (uint64_t *)malloc(sizeof(uint64_t) * n * link_count);
+  float *d = (float *)malloc(sizeof(float) * n * link_count);
+  uint64_t *len = (uint64_t *)malloc(sizeof(uint64_t) * n);
+  orc_link_search(ix, lft, sp, link_count, 0, n, ids, d, len, threads);
+  uint64_t added = orc_link_apply(ix, lft, link_count, ids, d, len, threads);
+  free(ids); free(d); free(len);
   return added;
 }
 
 /* ---------------------------------------------------------------- recall / improve */
 
-/* stochastic_recall_at  src/lib.rs:1463-1499 */
-float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_params *op, int threads) {
+/* hits among sample[first, first+count) of stochastic_recall_at  src/lib.rs:1463-1499 */
+int orc_recall_hits(const orc_index *ix, uint32_t at, const orc_opt_params *op, uint64_t first, uint64_t count,
+                    uint64_t *out_hits, uint64_t *out_selection, int threads) {
   const orc_layer *L = &ix->layers[at];
   uint64_t total = L->node_count;
   uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
@@ -454,6 +548,8 @@ float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_p
   uint64_t *vecs = (uint64_t *)malloc(sizeof(uint64_t) * total);
   memcpy(vecs, L->nodes, sizeof(uint64_t) * total);
   if (selection != total) orc_shuffle_u64(vecs, total, 42); /* StdRng::seed_from_u64(42) */
+  if (first > selection) first = selection;
+  if (first + count > selection) count = selection - first;
   uint64_t cap = op->search.number_of_candidates;
   uint64_t relevant = 0;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
@@ -462,7 +558,7 @@ float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_p
     uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
     float *od = (float *)malloc(sizeof(float) * cap);
 #pragma omp for schedule(dynamic, 16) reduction(+ : relevant)
-    for (uint64_t k = 0; k < selection; k++) {
+    for (uint64_t k = first; k < first + count; k++) {
       uint64_t len = 0;
       /* self.search(Stored(vid), op.search): the whole stack  :1488-1491 */
       orc_search_sc(ix, NULL, vecs[k], op->search, 0, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
@@ -477,7 +573,16 @@ float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_p
     orc_scratch_free(sc);
   }
   free(vecs);
-  return (float)relevant / (float)selection;
+  *out_hits = relevant;
+  if (out_selection) *out_selection = selection;
+  return 0;
+}
+
+/* stochastic_recall_at  src/lib.rs:1463-1499 */
+float orc_stochastic_recall_at(const orc_index *ix, uint32_t at, const orc_opt_params *op, int threads) {
+  uint64_t hits = 0, selection = 0;
+  orc_recall_hits(ix, at, op, 0, UINT64_MAX / 2, &hits, &selection, threads);
+  return (float)hits / (float)selection;
 }
 
 /* improve_neighbors_upto  src/lib.rs:1515-1544 */

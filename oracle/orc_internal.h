@@ -7,7 +7,12 @@ struct orc_index {
   orc_store store;
   uint32_t layer_count;
   orc_layer *layers; /* top first  (src/lib.rs:587) */
+  /* layer under construction (phase API of orc_build.c) */
+  uint64_t *p_vs, *p_gm, *p_gstart, *p_gsize;
+  uint64_t p_n, p_W, p_K;
+  int p_grouped;
 };
+void orc_pending_free(orc_index *ix);
 
 /* visit_queue entry: (NodeId, f32, NodeDistance{hops,index_sum})  src/lib.rs:182,162-173 */
 typedef struct {

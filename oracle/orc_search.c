@@ -29,6 +29,7 @@ void orc_index_free(orc_index *ix) {
     free(ix->layers[i].neighbors);
   }
   free(ix->layers);
+  orc_pending_free(ix);
   free(ix);
 }
 

@@ -72,6 +72,16 @@ SYMBOLS = {
     "phnsw_search_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp]),
     "phnsw_last_search_kernel_ms": (_i32, [_vp, C.POINTER(_f32)]),
+    "phnsw_index_create": (_i32, [_vp, C.POINTER(BuildParams), _pp]),
+    "phnsw_build_plan": (_i32, [_vp, _u64, C.POINTER(BuildParams), _vp, _vp, _u32, C.POINTER(_u32)]),
+    "phnsw_layer_begin": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams), C.POINTER(_i32)]),
+    "phnsw_layer_init_search_device": (_i32, [_vp, C.POINTER(BuildParams), _u64, _u64, _vp, _vp, _vp]),
+    "phnsw_layer_seed_device": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
+    "phnsw_layer_finish_device": (_i32, [_vp, _vp, _vp]),
+    "phnsw_link_search_device": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, _u64, _u64, _vp, _vp, _vp]),
+    "phnsw_link_apply_device": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "phnsw_recall_hits": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), _u64, _u64, C.POINTER(_u64),
+                                 C.POINTER(_u64)]),
     "phnsw_knn": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
 }
 

@@ -423,6 +423,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   if (!ix) return;
   hipSetDevice(ix->store->device);
   for (auto &l : ix->layers) ph_layer_free(l);
+  ph_pending_free(ix);
   ph_workspace_free(ix->ws);
   phnsw_store_destroy(ix->store);
   delete ix;

@@ -115,12 +115,12 @@ __device__ __forceinline__ float key_dist(uint64_t key) {
 
 // search results (VectorIds) -> this layer's NodeIds, self dropped
 // initial_vector_distances + the binary_search map  search.rs:54-62, 73-82
-__global__ void ph_init_from_search_kernel(const uint32_t *nodes, uint32_t n, const uint32_t *vec2node,
-                                           const uint32_t *res_ids, const float *res_d, const uint32_t *res_len,
-                                           uint32_t K, uint32_t *init_ids, float *init_d, uint32_t *init_len,
-                                           uint32_t *bad) {
+__global__ void ph_init_from_search_kernel(const uint32_t *nodes, uint32_t count, uint32_t n,
+                                           const uint32_t *vec2node, const uint32_t *res_ids, const float *res_d,
+                                           const uint32_t *res_len, uint32_t K, uint32_t *init_ids, float *init_d,
+                                           uint32_t *init_len, uint32_t *bad) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= count) return;
   uint32_t self = nodes[i];
   uint32_t m = 0, len = res_len[i];
   for (uint32_t k = 0; k < len && k < K; k++) {
@@ -153,7 +153,7 @@ struct PhSeedArgs {
   uint64_t layer_count;  // self.layer_count() in the seed expression  lib.rs:729-731
   uint64_t seed;
   uint32_t first, count;  // node range handled by this launch
-  uint32_t *rows;
+  uint32_t *rows;  // [count][W], row of node i at (i - first)
   float *rows_d;
 };
 
@@ -293,14 +293,14 @@ __global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
       uint64_t km = __ballot(keep);
       uint32_t at = outn + __popcll(km & lt);
       if (keep && at < a.W) {
-        a.rows[(uint64_t)i * a.W + at] = (uint32_t)kj & IDM;
-        a.rows_d[(uint64_t)i * a.W + at] = key_dist(kj);
+        a.rows[(uint64_t)(i - a.first) * a.W + at] = (uint32_t)kj & IDM;
+        a.rows_d[(uint64_t)(i - a.first) * a.W + at] = key_dist(kj);
       }
       outn += __popcll(km);
     }
     for (uint32_t j = std::min(outn, a.W) + lane; j < a.W; j += 64) {
-      a.rows[(uint64_t)i * a.W + j] = PH_EMPTY32;
-      a.rows_d[(uint64_t)i * a.W + j] = PH_FMAX;
+      a.rows[(uint64_t)(i - a.first) * a.W + j] = PH_EMPTY32;
+      a.rows_d[(uint64_t)(i - a.first) * a.W + j] = PH_FMAX;
     }
     __syncthreads();
   }
@@ -695,8 +695,31 @@ static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &no
   return 0;
 }
 
-static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
-                               const phnsw_build_params *bp) {
+// ---- generate_layer in phases.  A driver that shards the node range over several GPUs
+// calls begin / init_search(range) / seed(range) / finish with an all-gather between the
+// phases (parallel_hnsw_amd/sharded.py); the single-GPU entry point runs the same phases
+// over the whole range.
+
+struct PhPendingLayer {
+  PhLayerHost L;
+  uint32_t K = 0;
+  bool grouped = false;
+  DevBuf<uint32_t> gm, gstart, gsize;
+};
+
+static void pending_drop(phnsw_index *ix) {
+  if (ix->pending) {
+    ph_layer_free(ix->pending->L);
+    delete ix->pending;
+    ix->pending = nullptr;
+  }
+}
+void ph_pending_free(phnsw_index *ix) { pending_drop(ix); }
+
+// begin: validate, sort, upload nodes + id map, allocate rows.  *needs_phases = 0 when the
+// layer was completed here (first layer of a stack: all-pairs seeding, n < order).
+static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
+                            const phnsw_build_params *bp, int *needs_phases) {
   const phnsw_store *s = ix->store;
   if (!vids || n64 == 0 || W64 == 0 || W64 > 64 || n64 >= 0x7FFFFFFFull || !bp) {
     ph_set_error("generate_layer: need 1 <= n < 2^31 nodes and 1 <= neighborhood_size <= 64");
@@ -710,8 +733,13 @@ static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n
     ph_set_error("dim %u unsupported (max 1536)", s->dim);
     return PHNSW_E_UNSUPPORTED;
   }
+  const uint32_t K = (uint32_t)bp->initial_partition_search.number_of_candidates;
+  if (!ix->layers.empty() && (K == 0 || K > 64)) {
+    ph_set_error("initial_partition_search.number_of_candidates must be 1..64 (got %u)", K);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  pending_drop(ix);
   uint32_t n = (uint32_t)n64, W = (uint32_t)W64;
-  PhTimer tm("generate_layer", n);
   std::vector<uint32_t> nodes(n);
   for (uint32_t i = 0; i < n; i++) {
     if (vids[i] >= s->n) {
@@ -726,173 +754,295 @@ static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n
       ph_set_error("generate_layer: duplicate VectorId %u", nodes[i]);
       return PHNSW_E_INVALID;
     }
-  // the new layer object: nodes + id map first (the seeding kernels need them), rows later
   std::vector<uint32_t> empty_rows((size_t)n * W, PH_EMPTY32);
-  PhLayerHost L;
-  PH_TRY(ph_layer_upload(ix, nodes.data(), empty_rows.data(), n, W, &L));
-  hipError_t e = hipMalloc(&L.nbr_dist, (size_t)n * W * 4);
-  if (e != hipSuccess) {
-    ph_layer_free(L);
-    return ph_hip_fail(e, "nbr_dist alloc", __FILE__, __LINE__);
+  PhPendingLayer *P = new PhPendingLayer();
+  int rc = ph_layer_upload(ix, nodes.data(), empty_rows.data(), n, W, &P->L);
+  if (!rc) {
+    hipError_t e = hipMalloc(&P->L.nbr_dist, (size_t)n * W * 4);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "nbr_dist alloc", __FILE__, __LINE__);
   }
-  int rc = 0;
+  if (rc) {
+    ph_layer_free(P->L);
+    delete P;
+    return rc;
+  }
+  P->K = K;
+  ix->pending = P;
   if (ix->layers.empty()) {
     std::vector<uint32_t> rows;
     std::vector<float> rows_d;
     rc = generate_first_layer(ix, nodes, W, bp, rows, rows_d);
+    DevBuf<uint32_t> r;
+    DevBuf<float> rd;
+    if (!rc) rc = r.alloc(rows.size());
+    if (!rc) rc = rd.alloc(rows_d.size());
     if (!rc) {
-      e = hipMemcpy(L.neighbors, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(L.nbr_dist, rows_d.data(), rows_d.size() * 4, hipMemcpyHostToDevice);
+      hipError_t e = hipMemcpy(r.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(rd.p, rows_d.data(), rows_d.size() * 4, hipMemcpyHostToDevice);
       if (e != hipSuccess) rc = ph_hip_fail(e, "first layer upload", __FILE__, __LINE__);
     }
-  } else {
-    const phnsw_search_params ips = bp->initial_partition_search;
-    const uint32_t K = (uint32_t)ips.number_of_candidates;
-    if (K == 0 || K > 64) {
-      ph_set_error("initial_partition_search.number_of_candidates must be 1..64 (got %u)", K);
-      rc = PHNSW_E_UNSUPPORTED;
-    }
-    DevBuf<uint32_t> res_ids, res_len, init_ids, init_len, bad, d_gm, d_gstart, d_gsize;
-    DevBuf<float> res_d, init_d;
-    if (!rc) rc = res_ids.alloc((size_t)n * K);
-    if (!rc) rc = res_d.alloc((size_t)n * K);
-    if (!rc) rc = res_len.alloc(n);
-    if (!rc) rc = init_ids.alloc((size_t)n * K);
-    if (!rc) rc = init_d.alloc((size_t)n * K);
-    if (!rc) rc = init_len.alloc(n);
-    if (!rc) rc = bad.alloc(1);
-    // 1. generate_initial_partitions: search the layers above for every node  search.rs:32-71
-    if (!rc) rc = search_stored(ix, L.nodes, n, &ips, 0, nullptr, res_ids.p, res_d.p, res_len.p, 0, nullptr);
-    std::vector<uint32_t> key(n), h_len(n);
-    std::vector<float> keyd(n);
-    if (!rc) {
-      hipMemsetAsync(bad.p, 0, 4, 0);
-      hipLaunchKernelGGL(ph_init_from_search_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
-                         L.identity ? nullptr : L.vec2node, res_ids.p, res_d.p, res_len.p, K, init_ids.p, init_d.p,
-                         init_len.p, bad.p);
-      uint32_t hbad = 0;
-      e = hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(h_len.data(), init_len.p, (size_t)n * 4, hipMemcpyDeviceToHost);
-      // first (nearest) super of every node: column 0 of the init lists
-      if (e == hipSuccess)
-        e = hipMemcpy2D(key.data(), 4, init_ids.p, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost);
-      if (e == hipSuccess)
-        e = hipMemcpy2D(keyd.data(), 4, init_d.p, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost);
-      if (e != hipSuccess)
-        rc = ph_hip_fail(e, "init readback", __FILE__, __LINE__);
-      else if (hbad) {
-        ph_set_error("generate_layer: %u search results are not nodes of the new layer (layers must be nested)", hbad);
-        rc = PHNSW_E_MISSING_NODE;
-      }
-    }
-    if (!rc) {
-      // 2. partition groups  lib.rs:711-713
-      for (uint32_t i = 0; i < n; i++)
-        if (h_len[i] == 0) {
-          key[i] = PH_EMPTY32;
-          keyd[i] = 0.f;
-        }
-      std::vector<uint32_t> gm, gstart, gsize;
-      build_groups(n, key, keyd, gm, gstart, gsize);
-      rc = d_gm.alloc(n);
-      if (!rc) rc = d_gstart.alloc(n + 1);
-      if (!rc) rc = d_gsize.alloc(n + 1);
-      if (!rc) {
-        e = hipMemcpy(d_gm.p, gm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_gstart.p, gstart.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_gsize.p, gsize.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = ph_hip_fail(e, "group upload", __FILE__, __LINE__);
-      }
-    }
-    if (!rc) {
-      // 3. neighbourhood seeding (K3)
-      PhSeedArgs a;
-      a.vecs = s->rows;
-      a.ld = s->ld;
-      a.nv4 = s->ld / 4;
-      a.metric = s->metric;
-      a.nodes = L.nodes;
-      a.n = n;
-      a.W = W;
-      a.K = K;
-      a.init_ids = init_ids.p;
-      a.init_d = init_d.p;
-      a.init_len = init_len.p;
-      a.gm = d_gm.p;
-      a.gstart = d_gstart.p;
-      a.gsize = d_gsize.p;
-      a.layer_count = ix->layers.size();
-      a.seed = bp->seed;
-      a.first = 0;
-      a.count = n;
-      a.rows = L.neighbors;
-      a.rows_d = L.nbr_dist;
-      dim3 g(wave_grid(n)), b(64);
-      switch (nv_for(a.nv4)) {
-        case 1:
-          hipLaunchKernelGGL(ph_seed_rows_kernel<1>, g, b, 0, 0, a);
-          break;
-        case 3:
-          hipLaunchKernelGGL(ph_seed_rows_kernel<3>, g, b, 0, 0, a);
-          break;
-        default:
-          hipLaunchKernelGGL(ph_seed_rows_kernel<6>, g, b, 0, 0, a);
-          break;
-      }
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipDeviceSynchronize();
-      if (e != hipSuccess) rc = ph_hip_fail(e, "seed rows", __FILE__, __LINE__);
-    }
-  }
-  if (!rc) {
-    // 4. make neighbourhoods bidirectional  lib.rs:789-815: every row entry (t, d) of node i
-    // proposes (i, d) to row t; evaluated against the snapshot
-    DevBuf<uint32_t> snap;
-    DevBuf<float> snap_d;
-    rc = snap.alloc((size_t)n * W);
-    if (!rc) rc = snap_d.alloc((size_t)n * W);
-    if (!rc) {
-      e = hipMemcpy(snap.p, L.neighbors, (size_t)n * W * 4, hipMemcpyDeviceToDevice);
-      if (e == hipSuccess) e = hipMemcpy(snap_d.p, L.nbr_dist, (size_t)n * W * 4, hipMemcpyDeviceToDevice);
-      if (e != hipSuccess) rc = ph_hip_fail(e, "snapshot", __FILE__, __LINE__);
-    }
-    if (!rc) rc = apply_proposals(L, snap.p, snap_d.p, W, nullptr);
-  }
-  if (rc) {
-    ph_layer_free(L);
+    int layer_finish_impl(phnsw_index *, const uint32_t *, const float *);
+    if (!rc) rc = layer_finish_impl(ix, r.p, rd.p);
+    if (rc) pending_drop(ix);
+    *needs_phases = 0;
     return rc;
   }
-  ix->layers.push_back(L);
+  *needs_phases = 1;
   return 0;
+}
+
+// 1. generate_initial_partitions for nodes [first, first+count)  search.rs:32-71:
+// out_* are [count][K] (NodeIds of the new layer, self dropped) + [count] lengths
+static int layer_init_search_impl(phnsw_index *ix, const phnsw_build_params *bp, uint32_t first, uint32_t count,
+                                  uint32_t *out_ids, float *out_d, uint32_t *out_len) {
+  PhPendingLayer *P = ix->pending;
+  if (!P || first + (uint64_t)count > P->L.n_nodes) {
+    ph_set_error("layer_init_search: no pending layer or range out of bounds");
+    return PHNSW_E_INVALID;
+  }
+  if (count == 0) return 0;
+  const uint32_t K = P->K;
+  DevBuf<uint32_t> res_ids, res_len, bad;
+  DevBuf<float> res_d;
+  PH_TRY(res_ids.alloc((size_t)count * K));
+  PH_TRY(res_d.alloc((size_t)count * K));
+  PH_TRY(res_len.alloc(count));
+  PH_TRY(bad.alloc(1));
+  PH_TRY(search_stored(ix, P->L.nodes + first, count, &bp->initial_partition_search, 0, nullptr, res_ids.p, res_d.p,
+                       res_len.p, 0, nullptr));
+  PH_HIP(hipMemsetAsync(bad.p, 0, 4, 0));
+  hipLaunchKernelGGL(ph_init_from_search_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, P->L.nodes + first, count,
+                     P->L.n_nodes, P->L.identity ? nullptr : P->L.vec2node, res_ids.p, res_d.p, res_len.p, K, out_ids,
+                     out_d, out_len, bad.p);
+  PH_HIP(hipGetLastError());
+  uint32_t hbad = 0;
+  PH_HIP(hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost));
+  if (hbad) {
+    ph_set_error("generate_layer: %u search results are not nodes of the new layer (layers must be nested)", hbad);
+    return PHNSW_E_MISSING_NODE;
+  }
+  return 0;
+}
+
+// 2.+3. partition groups from the FULL init lists (host, replicated on every rank), then the
+// seeding kernel K3 for nodes [first, first+count); out_rows [count][W]
+static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const uint32_t *init_ids, const float *init_d,
+                           const uint32_t *init_len, uint32_t first, uint32_t count, uint32_t *out_rows,
+                           float *out_rows_d) {
+  PhPendingLayer *P = ix->pending;
+  if (!P || first + (uint64_t)count > P->L.n_nodes) {
+    ph_set_error("layer_seed: no pending layer or range out of bounds");
+    return PHNSW_E_INVALID;
+  }
+  const phnsw_store *s = ix->store;
+  const uint32_t n = P->L.n_nodes, K = P->K, W = P->L.W;
+  if (!P->grouped) {
+    std::vector<uint32_t> key(n), h_len(n);
+    std::vector<float> keyd(n);
+    PH_HIP(hipMemcpy(h_len.data(), init_len, (size_t)n * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy2D(key.data(), 4, init_ids, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy2D(keyd.data(), 4, init_d, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++)
+      if (h_len[i] == 0) {
+        key[i] = PH_EMPTY32;
+        keyd[i] = 0.f;
+      }
+    std::vector<uint32_t> gm, gstart, gsize;
+    build_groups(n, key, keyd, gm, gstart, gsize);  // lib.rs:711-713
+    PH_TRY(P->gm.alloc(n));
+    PH_TRY(P->gstart.alloc(n + 1));
+    PH_TRY(P->gsize.alloc(n + 1));
+    PH_HIP(hipMemcpy(P->gm.p, gm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    PH_HIP(hipMemcpy(P->gstart.p, gstart.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    PH_HIP(hipMemcpy(P->gsize.p, gsize.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    P->grouped = true;
+  }
+  if (count == 0) return 0;
+  PhSeedArgs a;
+  a.vecs = s->rows;
+  a.ld = s->ld;
+  a.nv4 = s->ld / 4;
+  a.metric = s->metric;
+  a.nodes = P->L.nodes;
+  a.n = n;
+  a.W = W;
+  a.K = K;
+  a.init_ids = init_ids;
+  a.init_d = init_d;
+  a.init_len = init_len;
+  a.gm = P->gm.p;
+  a.gstart = P->gstart.p;
+  a.gsize = P->gsize.p;
+  a.layer_count = ix->layers.size();
+  a.seed = bp->seed;
+  a.first = first;
+  a.count = count;
+  a.rows = out_rows;
+  a.rows_d = out_rows_d;
+  dim3 g(wave_grid(count)), b(64);
+  switch (nv_for(a.nv4)) {
+    case 1:
+      hipLaunchKernelGGL(ph_seed_rows_kernel<1>, g, b, 0, 0, a);
+      break;
+    case 3:
+      hipLaunchKernelGGL(ph_seed_rows_kernel<3>, g, b, 0, 0, a);
+      break;
+    default:
+      hipLaunchKernelGGL(ph_seed_rows_kernel<6>, g, b, 0, 0, a);
+      break;
+  }
+  PH_HIP(hipGetLastError());
+  PH_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+// 4. make neighbourhoods bidirectional  lib.rs:789-815: every row entry (t, d) of node i
+// proposes (i, d) to row t, evaluated against the seeded rows (the snapshot); then the layer
+// joins the stack
+int layer_finish_impl(phnsw_index *ix, const uint32_t *rows, const float *rows_d) {
+  PhPendingLayer *P = ix->pending;
+  if (!P) {
+    ph_set_error("layer_finish: no pending layer");
+    return PHNSW_E_INVALID;
+  }
+  size_t cnt = (size_t)P->L.n_nodes * P->L.W;
+  PH_HIP(hipMemcpy(P->L.neighbors, rows, cnt * 4, hipMemcpyDeviceToDevice));
+  PH_HIP(hipMemcpy(P->L.nbr_dist, rows_d, cnt * 4, hipMemcpyDeviceToDevice));
+  PH_TRY(apply_proposals(P->L, rows, rows_d, P->L.W, nullptr));
+  ix->layers.push_back(P->L);
+  P->L = PhLayerHost();
+  pending_drop(ix);
+  return 0;
+}
+
+static int generate_layer_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
+                               const phnsw_build_params *bp) {
+  PhTimer tm("generate_layer", n64);
+  int phases = 0;
+  PH_TRY(layer_begin_impl(ix, vids, n64, W64, bp, &phases));
+  if (!phases) return 0;
+  uint32_t n = (uint32_t)n64, W = (uint32_t)W64, K = ix->pending->K;
+  DevBuf<uint32_t> init_ids, init_len, rows;
+  DevBuf<float> init_d, rows_d;
+  int rc = init_ids.alloc((size_t)n * K);
+  if (!rc) rc = init_d.alloc((size_t)n * K);
+  if (!rc) rc = init_len.alloc(n);
+  if (!rc) rc = rows.alloc((size_t)n * W);
+  if (!rc) rc = rows_d.alloc((size_t)n * W);
+  if (!rc) rc = layer_init_search_impl(ix, bp, 0, n, init_ids.p, init_d.p, init_len.p);
+  if (!rc) rc = layer_seed_impl(ix, bp, init_ids.p, init_d.p, init_len.p, 0, n, rows.p, rows_d.p);
+  if (!rc) rc = layer_finish_impl(ix, rows.p, rows_d.p);
+  if (rc) pending_drop(ix);
+  return rc;
 }
 
 // ------------------------------------------------------------------ link / recall / improve
 
-// link_nodes_in_layer_to_better_neighbors over all nodes  lib.rs:1070-1154
-static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp, uint64_t link_count,
-                           uint64_t *out_added) {
-  if (lft >= ix->layers.size() || link_count == 0 || link_count > sp->number_of_candidates) {
-    ph_set_error("link_layer: layer %u out of range or link_count %llu not in 1..number_of_candidates", lft,
+// link round, phase 1: searches of nodes [first, first+count) against the unmodified layer
+// search_layers(Stored(vector), sp, &pseudo_stack, Some(vector))  lib.rs:1112-1117;
+// out_ids [count][M] VectorIds of the best M results
+static int link_search_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp, uint64_t link_count,
+                            uint32_t first, uint32_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len) {
+  if (lft >= ix->layers.size() || link_count == 0 || link_count > sp->number_of_candidates ||
+      first + (uint64_t)count > ix->layers[lft].n_nodes) {
+    ph_set_error("link_search: layer %u / range out of bounds or link_count %llu not in 1..number_of_candidates", lft,
                  (unsigned long long)link_count);
     return PHNSW_E_INVALID;
   }
+  if (count == 0) return 0;
   PhLayerHost &L = ix->layers[lft];
-  PhTimer tm("link_layer", L.n_nodes);
+  return search_stored(ix, L.nodes + first, count, sp, lft + 1, L.nodes + first, out_ids, out_d, out_len,
+                       (uint32_t)link_count, nullptr);
+}
+
+// link round, phase 2: all proposals -> rows (K5)  lib.rs:1118-1147
+static int link_apply_impl(phnsw_index *ix, uint32_t lft, uint64_t link_count, const uint32_t *res_ids,
+                           const float *res_d, const uint32_t *res_len, uint64_t *out_added) {
+  if (lft >= ix->layers.size() || link_count == 0) {
+    ph_set_error("link_apply: layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  PhLayerHost &L = ix->layers[lft];
   PH_TRY(ensure_row_dist(ix, L));
   uint32_t n = L.n_nodes, M = (uint32_t)link_count;
-  DevBuf<uint32_t> res_ids, res_len, tgt;
+  DevBuf<uint32_t> tgt;
+  PH_TRY(tgt.alloc((size_t)n * M));
+  hipLaunchKernelGGL(ph_link_targets_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
+                     L.identity ? nullptr : L.vec2node, res_ids, res_len, M, tgt.p);
+  PH_HIP(hipGetLastError());
+  return apply_proposals(L, tgt.p, res_d, M, out_added);
+}
+
+// link_nodes_in_layer_to_better_neighbors over all nodes  lib.rs:1070-1154
+static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp, uint64_t link_count,
+                           uint64_t *out_added) {
+  if (lft >= ix->layers.size()) {
+    ph_set_error("link_layer: layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  uint32_t n = ix->layers[lft].n_nodes, M = (uint32_t)link_count;
+  PhTimer tm("link_layer", n);
+  DevBuf<uint32_t> res_ids, res_len;
   DevBuf<float> res_d;
   PH_TRY(res_ids.alloc((size_t)n * M));
   PH_TRY(res_d.alloc((size_t)n * M));
   PH_TRY(res_len.alloc(n));
-  PH_TRY(tgt.alloc((size_t)n * M));
-  // search_layers(Stored(vector), sp, &pseudo_stack, Some(vector)): the rows are only
-  // rewritten after every search has finished, which is the clone of lib.rs:1097-1100
-  PH_TRY(search_stored(ix, L.nodes, n, sp, lft + 1, L.nodes, res_ids.p, res_d.p, res_len.p, M, nullptr));
-  hipLaunchKernelGGL(ph_link_targets_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
-                     L.identity ? nullptr : L.vec2node, res_ids.p, res_len.p, M, tgt.p);
-  PH_HIP(hipGetLastError());
-  return apply_proposals(L, tgt.p, res_d.p, M, out_added);
+  PH_TRY(link_search_impl(ix, lft, sp, link_count, 0, n, res_ids.p, res_d.p, res_len.p));
+  return link_apply_impl(ix, lft, link_count, res_ids.p, res_d.p, res_len.p, out_added);
+}
+
+// the sample of stochastic_recall_at  lib.rs:1468-1483
+static std::vector<uint32_t> recall_sample(phnsw_index *ix, uint32_t at, const phnsw_optimization_params *op, int *rc) {
+  const PhLayerHost &L = ix->layers[at];
+  uint64_t total = L.n_nodes;
+  uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
+  selection = std::min<uint64_t>(std::max<uint64_t>(selection, 1), total);
+  std::vector<uint32_t> h_nodes(total);
+  hipError_t e = hipMemcpy(h_nodes.data(), L.nodes, total * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    *rc = ph_hip_fail(e, "recall sample", __FILE__, __LINE__);
+    return {};
+  }
+  std::vector<uint64_t> vecs(h_nodes.begin(), h_nodes.end());
+  if (selection != total) ph_shuffle_u64(vecs.data(), total, 42);  // StdRng::seed_from_u64(42)
+  std::vector<uint32_t> q(selection);
+  for (uint64_t i = 0; i < selection; i++) q[i] = (uint32_t)vecs[i];
+  *rc = 0;
+  return q;
+}
+
+// hits among sample[first, first+count): self.search(Stored(vid), op.search) over the whole
+// stack, "any result == vid"  lib.rs:1485-1494
+static int recall_hits_impl(phnsw_index *ix, uint32_t at, const phnsw_optimization_params *op, uint64_t first,
+                            uint64_t count, uint64_t *out_hits, uint64_t *out_selection) {
+  if (at >= ix->layers.size()) {
+    ph_set_error("stochastic_recall_at: layer %u out of range", at);
+    return PHNSW_E_INVALID;
+  }
+  int rc = 0;
+  std::vector<uint32_t> q = recall_sample(ix, at, op, &rc);
+  if (rc) return rc;
+  if (out_selection) *out_selection = q.size();
+  if (first > q.size()) first = q.size();
+  if (first + count > q.size()) count = q.size() - first;
+  *out_hits = 0;
+  if (count == 0) return 0;
+  uint32_t nq = (uint32_t)count;
+  DevBuf<uint32_t> qd, ids, len, hit;
+  DevBuf<float> d;
+  PH_TRY(qd.alloc(nq));
+  PH_TRY(ids.alloc(nq));
+  PH_TRY(d.alloc(nq));
+  PH_TRY(len.alloc(nq));
+  PH_TRY(hit.alloc(nq));
+  PH_HIP(hipMemcpy(qd.p, q.data() + first, (size_t)nq * 4, hipMemcpyHostToDevice));
+  PH_TRY(search_stored(ix, qd.p, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
+  std::vector<uint32_t> h(nq);
+  PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  uint64_t relevant = 0;
+  for (uint32_t x : h) relevant += x;
+  *out_hits = relevant;
+  return 0;
 }
 
 // stochastic_recall_at  lib.rs:1463-1499
@@ -901,33 +1051,10 @@ static int recall_impl(phnsw_index *ix, uint32_t at, const phnsw_optimization_pa
     ph_set_error("stochastic_recall_at: layer %u out of range", at);
     return PHNSW_E_INVALID;
   }
-  const PhLayerHost &L = ix->layers[at];
-  PhTimer tm("stochastic_recall_at", L.n_nodes);
-  uint64_t total = L.n_nodes;
-  uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
-  selection = std::min<uint64_t>(std::max<uint64_t>(selection, 1), total);
-  std::vector<uint32_t> h_nodes(total);
-  PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, total * 4, hipMemcpyDeviceToHost));
-  std::vector<uint64_t> vecs(h_nodes.begin(), h_nodes.end());
-  if (selection != total) ph_shuffle_u64(vecs.data(), total, 42);  // StdRng::seed_from_u64(42)
-  std::vector<uint32_t> q(selection);
-  for (uint64_t i = 0; i < selection; i++) q[i] = (uint32_t)vecs[i];
-  uint32_t nq = (uint32_t)selection;
-  DevBuf<uint32_t> qd, ids, len, hit;
-  DevBuf<float> d;
-  PH_TRY(qd.alloc(nq));
-  PH_TRY(ids.alloc(nq));
-  PH_TRY(d.alloc(nq));
-  PH_TRY(len.alloc(nq));
-  PH_TRY(hit.alloc(nq));
-  PH_HIP(hipMemcpy(qd.p, q.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
-  // self.search(Stored(vid), op.search): the whole stack  lib.rs:1488-1491
-  PH_TRY(search_stored(ix, qd.p, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
-  std::vector<uint32_t> h(nq);
-  PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  uint64_t relevant = 0;
-  for (uint32_t x : h) relevant += x;
-  *out = (float)relevant / (float)selection;
+  PhTimer tm("stochastic_recall_at", ix->layers[at].n_nodes);
+  uint64_t hits = 0, selection = 0;
+  PH_TRY(recall_hits_impl(ix, at, op, 0, UINT64_MAX / 2, &hits, &selection));
+  *out = (float)hits / (float)selection;
   return 0;
 }
 
@@ -1039,6 +1166,78 @@ extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
   return improve_index_impl(ix, bp, cb, user, out_recall);
+}
+
+// ---- phase entry points for multi-GPU drivers (device buffers, u32 ids) ----
+extern "C" int phnsw_layer_begin(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
+                                 const phnsw_build_params *bp, int *needs_phases) {
+  PH_TRY(enter(ix));
+  if (!needs_phases) return PHNSW_E_INVALID;
+  return layer_begin_impl(ix, vids, n, neighborhood_size, bp, needs_phases);
+}
+extern "C" int phnsw_layer_init_search_device(phnsw_index *ix, const phnsw_build_params *bp, uint64_t first,
+                                              uint64_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len) {
+  PH_TRY(enter(ix));
+  if (!bp) return PHNSW_E_INVALID;
+  return layer_init_search_impl(ix, bp, (uint32_t)first, (uint32_t)count, out_ids, out_d, out_len);
+}
+extern "C" int phnsw_layer_seed_device(phnsw_index *ix, const phnsw_build_params *bp, const uint32_t *init_ids,
+                                       const float *init_d, const uint32_t *init_len, uint64_t first, uint64_t count,
+                                       uint32_t *out_rows, float *out_rows_d) {
+  PH_TRY(enter(ix));
+  if (!bp) return PHNSW_E_INVALID;
+  return layer_seed_impl(ix, bp, init_ids, init_d, init_len, (uint32_t)first, (uint32_t)count, out_rows, out_rows_d);
+}
+extern "C" int phnsw_layer_finish_device(phnsw_index *ix, const uint32_t *rows, const float *rows_d) {
+  PH_TRY(enter(ix));
+  return layer_finish_impl(ix, rows, rows_d);
+}
+extern "C" int phnsw_link_search_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                                        uint64_t link_count, uint64_t first, uint64_t count, uint32_t *out_ids,
+                                        float *out_d, uint32_t *out_len) {
+  PH_TRY(enter(ix));
+  if (!sp) return PHNSW_E_INVALID;
+  return link_search_impl(ix, layer_from_top, sp, link_count, (uint32_t)first, (uint32_t)count, out_ids, out_d, out_len);
+}
+extern "C" int phnsw_link_apply_device(phnsw_index *ix, uint32_t layer_from_top, uint64_t link_count,
+                                       const uint32_t *ids, const float *d, const uint32_t *len, uint64_t *out_added) {
+  PH_TRY(enter(ix));
+  return link_apply_impl(ix, layer_from_top, link_count, ids, d, len, out_added);
+}
+extern "C" int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
+                                 uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection) {
+  PH_TRY(enter(ix));
+  if (!op || !out_hits) return PHNSW_E_INVALID;
+  return recall_hits_impl(ix, layer_from_top, op, first, count, out_hits, out_selection);
+}
+extern "C" int phnsw_index_create(phnsw_store *s, const phnsw_build_params *bp, phnsw_index **out) {
+  if (!s || !out) return PHNSW_E_INVALID;
+  PH_HIP(hipSetDevice(s->device));
+  phnsw_index *ix = new phnsw_index();
+  ix->store = s;
+  s->refcount++;
+  if (bp)
+    ix->bp = *bp;
+  else
+    phnsw_default_build_params(&ix->bp);
+  *out = ix;
+  return 0;
+}
+// the deterministic id shuffle of phnsw_build (lib.rs:832-833) and its layer sizes
+// (calculate_partitions lib.rs:1883-1899) for drivers that run the phases themselves
+extern "C" int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_build_params *bp, uint64_t *shuffled,
+                                uint64_t *layer_sizes, uint32_t max_layers, uint32_t *layer_count) {
+  if (!vids || !bp || !shuffled || !layer_sizes || !layer_count || n == 0 || bp->order < 2) {
+    ph_set_error("phnsw_build_plan: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  memcpy(shuffled, vids, n * 8);
+  ph_shuffle_u64(shuffled, n, bp->seed);
+  std::vector<uint64_t> parts = calculate_partitions(n, bp->order);
+  if (parts.size() > max_layers) return PHNSW_E_INVALID;
+  for (size_t i = 0; i < parts.size(); i++) layer_sizes[i] = parts[i];
+  *layer_count = (uint32_t)parts.size();
+  return 0;
 }
 
 // Hnsw::generate  lib.rs:825-893

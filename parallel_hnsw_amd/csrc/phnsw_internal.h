@@ -64,7 +64,9 @@ struct PhWorkspace {
   bool timed = false;
 };
 
+struct PhPendingLayer;
 struct phnsw_index {
+  PhPendingLayer *pending = nullptr;  // layer under construction (phase API, build.hip)
   phnsw_store *store = nullptr;
   std::vector<PhLayerHost> layers;  // top first (src/lib.rs:587)
   phnsw_build_params bp;
@@ -104,6 +106,7 @@ struct PhSearchArgs {
 };
 
 void ph_layer_free(PhLayerHost &l);
+void ph_pending_free(phnsw_index *ix);
 int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
                     PhLayerHost *out);
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,

@@ -1,0 +1,239 @@
+"""Index construction sharded over the GPUs of one node (BASELINE
+config 4): one process per GPU, `torch.distributed` over RCCL/xGMI.
+
+Every rank holds a replica of the vector store and of the graph.  Each build round is
+"every node of a layer runs a search against a snapshot, then proposes edges"
+(reference src/lib.rs:1097-1153; likewise the seeding steps of generate_layer
+lib.rs:700-787), so nodes are independent within a round:
+
+    rank r searches the node range [r*chunk, (r+1)*chunk)        (K2 / K3 kernels)
+    all-gather of the per-node results  (ids u32 + distances f32, n x M x 8 bytes)
+    every rank applies ALL results to its replica                 (K5, deterministic)
+
+so the replicas stay bit-identical and the only data-path collective is one all-gather per
+phase (plus an all-reduce of two integers for the recall estimate).  The control flow is the
+reference's (generate lib.rs:825-893, improve_index lib.rs:1546-1686, promotion excluded),
+the same as libphnsw's single-GPU `phnsw_build`.
+
+The driver is written against a small engine interface so that the CPU tests can run it
+under `gloo` with the oracle as the engine; `GpuEngine` is the product engine.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .hnsw import BuildParameters, Hnsw
+
+
+class TorchComm:
+    """all-gather / all-reduce over a torch.distributed group (nccl = RCCL on ROCm, gloo on CPU)"""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_gathered = 0
+
+    def all_gather(self, t):
+        if self.world == 1:
+            return t
+        import torch
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        self.bytes_gathered += out.numel() * out.element_size()
+        return out
+
+    def all_reduce_sum(self, values, device):
+        if self.world == 1:
+            return list(values)
+        import torch
+        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return [int(x) for x in t.tolist()]
+
+
+class GpuEngine:
+    """libphnsw's phase API over torch device tensors (u32 ids viewed as int32)"""
+
+    def __init__(self, store, bp=None, device=None):
+        import torch
+        self.torch = torch
+        self.store = store
+        self.bp = bp or BuildParameters()
+        self.device = device if device is not None else torch.device("cuda", store.device)
+        h = C.c_void_p()
+        check(lib().phnsw_index_create(store._h, C.byref(self.bp), C.byref(h)))
+        self.hnsw = Hnsw(store, h, self.bp)
+
+    # -- buffers
+    def empty(self, shape, kind):
+        dt = self.torch.float32 if kind == "f32" else self.torch.int32
+        return self.torch.empty(shape, dtype=dt, device=self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    # -- plan
+    def plan(self, vids):
+        vids = np.ascontiguousarray(vids, dtype=np.uint64)
+        sh = np.empty_like(vids)
+        sizes = np.zeros(64, dtype=np.uint64)
+        cnt = C.c_uint32()
+        check(lib().phnsw_build_plan(vids.ctypes.data_as(C.c_void_p), len(vids), C.byref(self.bp),
+                                     sh.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p), 64,
+                                     C.byref(cnt)))
+        return sh, [int(x) for x in sizes[:cnt.value]]
+
+    # -- generate_layer phases
+    def layer_begin(self, vids, W):
+        vids = np.ascontiguousarray(vids, dtype=np.uint64)
+        needs = C.c_int()
+        check(lib().phnsw_layer_begin(self.hnsw._h, vids.ctypes.data_as(C.c_void_p), len(vids), W, C.byref(self.bp),
+                                      C.byref(needs)))
+        return bool(needs.value), int(self.bp.initial_partition_search.number_of_candidates)
+
+    def layer_init_search(self, first, count, ids, d, ln):
+        check(lib().phnsw_layer_init_search_device(self.hnsw._h, C.byref(self.bp), first, count, self._ptr(ids),
+                                                   self._ptr(d), self._ptr(ln)))
+
+    def layer_seed(self, ids, d, ln, first, count, rows, rows_d):
+        check(lib().phnsw_layer_seed_device(self.hnsw._h, C.byref(self.bp), self._ptr(ids), self._ptr(d),
+                                            self._ptr(ln), first, count, self._ptr(rows), self._ptr(rows_d)))
+
+    def layer_finish(self, rows, rows_d):
+        check(lib().phnsw_layer_finish_device(self.hnsw._h, self._ptr(rows), self._ptr(rows_d)))
+
+    # -- link / recall phases
+    def layer_count(self):
+        return self.hnsw.layer_count()
+
+    def layer_nodes(self, lft):
+        n = C.c_uint64()
+        check(lib().phnsw_index_layer_info(self.hnsw._h, lft, C.byref(n), None))
+        return n.value
+
+    def link_search(self, lft, sp, M, first, count, ids, d, ln):
+        check(lib().phnsw_link_search_device(self.hnsw._h, lft, C.byref(sp), M, first, count, self._ptr(ids),
+                                             self._ptr(d), self._ptr(ln)))
+
+    def link_apply(self, lft, M, ids, d, ln):
+        added = C.c_uint64()
+        check(lib().phnsw_link_apply_device(self.hnsw._h, lft, M, self._ptr(ids), self._ptr(d), self._ptr(ln),
+                                            C.byref(added)))
+        return added.value
+
+    def recall_hits(self, at, op, first, count):
+        hits, sel = C.c_uint64(), C.c_uint64()
+        check(lib().phnsw_recall_hits(self.hnsw._h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel)))
+        return hits.value, sel.value
+
+
+class ShardedBuilder:
+    """Hnsw::generate with every per-node phase split over the ranks of `comm`"""
+
+    def __init__(self, engine, comm=None):
+        self.e = engine
+        self.comm = comm or TorchComm()
+        self.rank, self.world = self.comm.rank, self.comm.world
+        self.bp = engine.bp
+
+    def _range(self, n):
+        chunk = -(-n // self.world)
+        first = min(n, self.rank * chunk)
+        count = min(n, first + chunk) - first
+        return chunk, first, count
+
+    def _gather(self, t, n):
+        return self.comm.all_gather(t)[:n]
+
+    # generate_layer  lib.rs:675-823
+    def generate_layer(self, vids, W):
+        needs, K = self.e.layer_begin(vids, W)
+        if not needs:
+            return
+        n = len(vids)
+        chunk, first, count = self._range(n)
+        ids, d, ln = self.e.empty((chunk, K), "id"), self.e.empty((chunk, K), "f32"), self.e.empty((chunk,), "id")
+        self.e.layer_init_search(first, count, ids, d, ln)
+        ids_f, d_f, ln_f = self._gather(ids, n), self._gather(d, n), self._gather(ln, n)
+        rows, rows_d = self.e.empty((chunk, W), "id"), self.e.empty((chunk, W), "f32")
+        self.e.layer_seed(ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous(), first, count, rows, rows_d)
+        self.e.layer_finish(self._gather(rows, n).contiguous(), self._gather(rows_d, n).contiguous())
+
+    # link_layer_to_better_neighbors  lib.rs:1070-1154
+    def link_layer(self, lft, sp, M):
+        n = self.e.layer_nodes(lft)
+        chunk, first, count = self._range(n)
+        ids, d, ln = self.e.empty((chunk, M), "id"), self.e.empty((chunk, M), "f32"), self.e.empty((chunk,), "id")
+        self.e.link_search(lft, sp, M, first, count, ids, d, ln)
+        return self.e.link_apply(lft, M, self._gather(ids, n).contiguous(), self._gather(d, n).contiguous(),
+                                 self._gather(ln, n).contiguous())
+
+    # stochastic_recall_at  lib.rs:1463-1499
+    def stochastic_recall_at(self, at):
+        op = self.bp.optimization
+        total = self.e.layer_nodes(at)
+        selection = min(total, max(1, int(np.float32(total) * np.float32(op.recall_proportion))))
+        chunk, first, count = self._range(selection)
+        hits, sel = self.e.recall_hits(at, op, first, count)
+        assert sel == selection, (sel, selection)
+        (hits,) = self.comm.all_reduce_sum([hits], getattr(self.e, "device", "cpu"))
+        return float(np.float32(hits) / np.float32(selection))
+
+    # improve_neighbors_upto  lib.rs:1515-1544
+    def improve_neighbors_upto(self, upto, last_recall=None):
+        op = self.bp.optimization
+        last = np.float32(0.0 if last_recall is None else last_recall)
+        improvement = np.float32(1.0)
+        rounds = 0
+        while improvement >= np.float32(op.neighborhood_threshold) and last < np.float32(1.0):
+            for lft in range(upto):
+                self.link_layer(lft, op.search, self.bp.neighborhood_size)
+            recall = np.float32(self.stochastic_recall_at(upto - 1))
+            improvement = recall - last
+            last = recall
+            rounds += 1
+            if self.bp.max_link_rounds and rounds >= self.bp.max_link_rounds:
+                break
+        return float(last)
+
+    # improve_index_at  lib.rs:1546-1603 (promotion not performed)
+    def improve_index_at(self, lft):
+        op = self.bp.optimization
+        recall = np.float32(self.stochastic_recall_at(lft))
+        improvement, bailout = np.float32(1.0), 1
+        while improvement >= np.float32(op.promotion_threshold) and recall < np.float32(1.0) and bailout != 0:
+            last, cur = recall, 0
+            while cur <= lft and bailout != 0:
+                recall = np.float32(self.improve_neighbors_upto(cur + 1))
+                cur += 1
+            bailout -= 1
+            improvement = recall - last
+        return float(recall)
+
+    # improve_index  lib.rs:1664-1686
+    def improve_index(self):
+        recall = self.stochastic_recall_at(self.e.layer_count() - 1)
+        for lft in range(self.e.layer_count()):
+            recall = self.improve_index_at(lft)
+        return recall
+
+    # Hnsw::generate  lib.rs:825-893
+    def generate(self, vids):
+        vs, sizes = self.e.plan(vids)
+        n = len(vs)
+        for i, size in enumerate(sizes):
+            length = min(size, n)
+            level = len(sizes) - i - 1
+            W = self.bp.zero_layer_neighborhood_size if level == 0 else self.bp.neighborhood_size
+            self.generate_layer(vs[:length], W)
+            self.improve_index()
+        return getattr(self.e, "hnsw", None)

@@ -142,3 +142,89 @@ def test_build_rejects_bad_input():
         ph.Hnsw.generate(store, np.array([0, 1, 1], dtype=np.uint64), gbp(order=2))
     with pytest.raises(ph.PhnswError):
         ph.Hnsw.generate(store, np.arange(9), gbp(zero_layer_neighborhood_size=65))
+
+
+def test_sharded_builder_single_rank_equals_phnsw_build():
+    """parallel_hnsw_amd.sharded (the multi-GPU driver) on one rank: same phases, same graph
+    as phnsw_build and as the oracle; the 2-rank split itself is covered on CPU (gloo)"""
+    n, dim = 3000, 64
+    rows = oracle.synth_rows(0, n, dim)
+    store = ph.VectorStore(rows[:, :dim])
+    eng = ph.GpuEngine(store, gbp(seed=4))
+
+    class OneRank:
+        rank, world, bytes_gathered = 0, 1, 0
+
+        def all_gather(self, t):
+            return t
+
+        def all_reduce_sum(self, v, device):
+            return list(v)
+
+    h = ph.ShardedBuilder(eng, OneRank()).generate(np.arange(n))
+    ref = ph.Hnsw.generate(store, np.arange(n), gbp(seed=4))
+    assert h.layer_count() == ref.layer_count()
+    for l in range(ref.layer_count()):
+        a, b = h._layer(l), ref._layer(l)
+        np.testing.assert_array_equal(a.nodes, b.nodes)
+        np.testing.assert_array_equal(a.neighbors, b.neighbors)
+    oix = oracle.Index.generate(rows, np.arange(n), obp(seed=4), dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    layers_equal(h, oix)
+
+
+def test_phase_api_ranges_compose():
+    """two half ranges through the phase API == one full range (what two GPUs would compute)"""
+    import torch
+    n, dim = 2000, 32
+    rows = oracle.synth_rows(0, n, dim)
+    store = ph.VectorStore(rows[:, :dim])
+    ref = ph.Hnsw.generate(store, np.arange(n), gbp(seed=2))
+
+    class TwoHalves:
+        """runs the driver twice per phase on one GPU by faking rank 0 then rank 1"""
+        bytes_gathered = 0
+
+        def __init__(self):
+            self.rank, self.world = 0, 1
+
+        def all_gather(self, t):
+            return t
+
+        def all_reduce_sum(self, v, device):
+            return list(v)
+
+    eng = ph.GpuEngine(store, gbp(seed=2))
+    b = ph.ShardedBuilder(eng, TwoHalves())
+    orig_range = b._range
+
+    # monkeypatch the phase calls to split every range in two launches
+    def split(fn, first_idx, count_idx):
+        def wrapped(*a):
+            a = list(a)
+            first, count = a[first_idx], a[count_idx]
+            h1 = count // 2
+            outs = [x for x in a if isinstance(x, torch.Tensor) and x.shape[0] == count and x is not None]
+            a1 = list(a); a1[count_idx] = h1
+            a2 = list(a); a2[first_idx] = first + h1; a2[count_idx] = count - h1
+            # output tensors are the trailing tensor args: give the second half offset views
+            for i, x in enumerate(a):
+                if i > count_idx and isinstance(x, torch.Tensor):
+                    a1[i] = x[:h1]
+                    a2[i] = x[h1:]
+            fn(*a1)
+            fn(*a2)
+        return wrapped
+
+    eng.layer_init_search = split(eng.layer_init_search, 0, 1)
+    eng.link_search = split(eng.link_search, 3, 4)
+    seed0 = eng.layer_seed
+
+    def seed_split(ids, d, ln, first, count, rows_, rows_d):
+        h1 = count // 2
+        seed0(ids, d, ln, first, h1, rows_[:h1], rows_d[:h1])
+        seed0(ids, d, ln, first + h1, count - h1, rows_[h1:], rows_d[h1:])
+
+    eng.layer_seed = seed_split
+    h = b.generate(np.arange(n))
+    for l in range(ref.layer_count()):
+        np.testing.assert_array_equal(h._layer(l).neighbors, ref._layer(l).neighbors)

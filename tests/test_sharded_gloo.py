@@ -1,0 +1,147 @@
+"""The N>1 build path on CPU: parallel_hnsw_amd.sharded.ShardedBuilder under a world_size-2
+`gloo` group with the oracle as the engine.  Checks the range split, padding, all-gather
+assembly and the replicated control flow: both ranks must end with exactly the graph a
+single process builds."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleEngine:
+    """engine interface of sharded.py backed by the CPU oracle (u64 ids as int64 tensors)"""
+
+    def __init__(self, rows, dim, bp, metric=0, threads=2):
+        import torch
+        import oracle
+        self.torch, self.oracle = torch, oracle
+        self.ix = oracle.Index(rows, dim=dim, metric=metric, sum_mode=oracle.SUM_BLOCKED64)
+        self.ix.set_sum_mode(oracle.SUM_BLOCKED64)
+        self.bp, self.threads, self.device = bp, threads, "cpu"
+        self.L = oracle.lib()
+
+    def empty(self, shape, kind):
+        return self.torch.empty(shape, dtype=self.torch.float32 if kind == "f32" else self.torch.int64)
+
+    @staticmethod
+    def _p(t):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+
+    def plan(self, vids):
+        vs = self.oracle.shuffle(np.asarray(vids, dtype=np.uint64), self.bp.seed)
+        return vs, self.oracle.calculate_partitions(len(vs), self.bp.order)
+
+    def layer_begin(self, vids, W):
+        v = np.ascontiguousarray(vids, dtype=np.uint64)
+        assert self.L.orc_layer_begin(self.ix.h, v.ctypes.data_as(C.c_void_p), len(v), W, C.byref(self.bp)) == 0
+        return True, int(self.L.orc_layer_init_stride(self.ix.h))
+
+    def layer_init_search(self, first, count, ids, d, ln):
+        assert self.L.orc_layer_init_search(self.ix.h, C.byref(self.bp), first, count, self._p(ids), self._p(d),
+                                            self._p(ln), self.threads) == 0
+
+    def layer_seed(self, ids, d, ln, first, count, rows, rows_d):
+        assert self.L.orc_layer_seed(self.ix.h, C.byref(self.bp), self._p(ids), self._p(d), self._p(ln), first, count,
+                                     self._p(rows), self._p(rows_d), self.threads) == 0
+
+    def layer_finish(self, rows, rows_d):
+        assert self.L.orc_layer_finish(self.ix.h, self._p(rows), self._p(rows_d), self.threads) == 0
+
+    def layer_count(self):
+        return self.ix.layer_count
+
+    def layer_nodes(self, lft):
+        return int(self.L.orc_index_layer(self.ix.h, lft).contents.node_count)
+
+    def link_search(self, lft, sp, M, first, count, ids, d, ln):
+        assert self.L.orc_link_search(self.ix.h, lft, sp, M, first, count, self._p(ids), self._p(d), self._p(ln),
+                                      self.threads) == 0
+
+    def link_apply(self, lft, M, ids, d, ln):
+        return int(self.L.orc_link_apply(self.ix.h, lft, M, self._p(ids), self._p(d), self._p(ln), self.threads))
+
+    def recall_hits(self, at, op, first, count):
+        hits, sel = C.c_uint64(), C.c_uint64()
+        assert self.L.orc_recall_hits(self.ix.h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel),
+                                      self.threads) == 0
+        return hits.value, sel.value
+
+
+CASES = [
+    dict(n=700, dim=16, kw=dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12, seed=3)),
+    dict(n=1501, dim=24, kw=dict(seed=1)),   # odd size: ranges of unequal length
+]
+
+
+def _worker(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import oracle
+    from parallel_hnsw_amd.sharded import ShardedBuilder, TorchComm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = oracle.synth_rows(0, case["n"], case["dim"])
+        bp = oracle.default_build_params(**case["kw"])
+        eng = OracleEngine(rows, case["dim"], bp)
+        comm = TorchComm()
+        b = ShardedBuilder(eng, comm)
+        b.generate(np.arange(case["n"], dtype=np.uint64))
+        layers = [eng.ix.layer(l) for l in range(eng.ix.layer_count)]
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), count=len(layers), gathered=comm.bytes_gathered,
+                 **{"nodes%d" % i: l[0] for i, l in enumerate(layers)},
+                 **{"nb%d" % i: l[1] for i, l in enumerate(layers)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d" % c["n"])
+def test_sharded_build_equals_single_process(case, tmp_path):
+    import torch.multiprocessing as mp
+    import oracle
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    rows = oracle.synth_rows(0, case["n"], case["dim"])
+    ref = oracle.Index.generate(rows, np.arange(case["n"]), oracle.default_build_params(**case["kw"]),
+                                dim=case["dim"], sum_mode=oracle.SUM_BLOCKED64, threads=4)
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert int(z["count"]) == ref.layer_count
+        assert int(z["gathered"]) > 0
+        for l in range(ref.layer_count):
+            nodes, nb = ref.layer(l)
+            np.testing.assert_array_equal(z["nodes%d" % l], nodes)
+            np.testing.assert_array_equal(z["nb%d" % l], nb, err_msg="rank %d layer %d" % (rank, l))
+
+
+def test_range_split_covers_everything():
+    from parallel_hnsw_amd.sharded import ShardedBuilder
+
+    class FakeComm:
+        def __init__(self, r, w):
+            self.rank, self.world = r, w
+
+    class FakeEngine:
+        bp = None
+
+    for n in (1, 2, 7, 8, 9, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                b = ShardedBuilder(FakeEngine(), FakeComm(r, w))
+                chunk, first, count = b._range(n)
+                assert count <= chunk and first + count <= n
+                assert first == min(n, r * chunk)
+                seen += list(range(first, first + count))
+            assert seen == list(range(n))
