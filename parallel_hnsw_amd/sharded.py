@@ -42,15 +42,19 @@ class TorchComm:
         if self.world == 1:
             return t
         import torch
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        staged = t.is_cuda and self.dist.get_backend(self.group) == "gloo"  # 1-GPU rehearsal only
+        src = t.cpu() if staged else t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+        self.dist.all_gather_into_tensor(out, src, group=self.group)
         self.bytes_gathered += out.numel() * out.element_size()
-        return out
+        return out.to(t.device) if staged else out
 
     def all_reduce_sum(self, values, device):
         if self.world == 1:
             return list(values)
         import torch
+        if self.dist.get_backend(self.group) == "gloo":
+            device = "cpu"
         t = torch.tensor(list(values), dtype=torch.int64, device=device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return [int(x) for x in t.tolist()]

@@ -228,3 +228,41 @@ def test_phase_api_ranges_compose():
     h = b.generate(np.arange(n))
     for l in range(ref.layer_count()):
         np.testing.assert_array_equal(h._layer(l).neighbors, ref._layer(l).neighbors)
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, dim = 3000, 64
+        store = ph.VectorStore.synthetic(n, dim, seed=42)
+        eng = ph.GpuEngine(store, ph.BuildParameters(seed=6))
+        comm = ph.TorchComm()
+        h = ph.ShardedBuilder(eng, comm).generate(np.arange(n))
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered,
+                 **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_rehearsal(tmp_path):
+    """two processes share the one GPU of the test box and exchange through gloo (RCCL needs
+    one GPU per rank); every device-side piece of the sharded build runs with real ranges"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    n, dim = 3000, 64
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    ref = ph.Hnsw.generate(store, np.arange(n), ph.BuildParameters(seed=6))
+    for r in range(2):
+        z = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert int(z["gathered"]) > 0
+        for l in range(ref.layer_count()):
+            np.testing.assert_array_equal(z["nb%d" % l], ref._layer(l).neighbors, err_msg="rank %d layer %d" % (r, l))
