@@ -58,9 +58,15 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" + BENCH_SHARE_GPU=1: 1-GPU rehearsal
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -207,7 +213,7 @@ def main():
             torch.cuda.synchronize()
             kms.append(index.kernel_ms())
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         rec = recall_at_10(run.result_ids(ef), gt)
