@@ -37,15 +37,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--dataset", default="clustered", choices=["clustered", "iid"])
     ap.add_argument("--ef", type=int, default=0, help="fix number_of_candidates (0 = sweep for recall@10>=0.95)")
     ap.add_argument("--probe-depth", type=int, default=0)
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--no-iid", action="store_true", help="skip the secondary iid-uniform measurement")
+    ap.add_argument("--skip-iid", dest="no_iid", action="store_true", help="skip the secondary iid-uniform measurement")
     args = ap.parse_args()
 
     import torch
