@@ -242,30 +242,7 @@ __global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
         // keep the readlane loop wave-uniform: inactive lanes still run it (nothing to do)
       }
       // compare_vec(Stored(vector_id), Stored(choice.1))  lib.rs:750-754
-      float myd = 0.f;
-      uint64_t rem = __ballot(act);
-      while (rem) {
-        int l0 = __builtin_ctzll(rem);
-        rem &= rem - 1;
-        int l1 = rem ? __builtin_ctzll(rem) : l0;
-        rem &= rem ? rem - 1 : 0;
-        int l2_ = rem ? __builtin_ctzll(rem) : l0;
-        rem &= rem ? rem - 1 : 0;
-        int l3 = rem ? __builtin_ctzll(rem) : l0;
-        rem &= rem ? rem - 1 : 0;
-        float p0 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l0) * a.ld), qv, a.nv4, lane, l2);
-        float p1 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l1) * a.ld), qv, a.nv4, lane, l2);
-        float p2 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l2_) * a.ld), qv, a.nv4, lane, l2);
-        float p3 = row_partial<NV>((const float4 *)(a.vecs + (uint64_t)rl32(vm, l3) * a.ld), qv, a.nv4, lane, l2);
-        p0 = wave_sum(p0);
-        p1 = wave_sum(p1);
-        p2 = wave_sum(p2);
-        p3 = wave_sum(p3);
-        if ((int)lane == l0) myd = finalize_metric(p0, a.metric);
-        if ((int)lane == l1) myd = finalize_metric(p1, a.metric);
-        if ((int)lane == l2_) myd = finalize_metric(p2, a.metric);
-        if ((int)lane == l3) myd = finalize_metric(p3, a.metric);
-      }
+      const float myd = batch_distances<NV>(a.vecs, a.ld, a.nv4, a.metric, l2, qv, __ballot(act), vm, lane);
       if (act) keys[len + k] = mkkey(myd, member);
     }
     __syncthreads();
@@ -445,14 +422,8 @@ __global__ __launch_bounds__(64) void ph_row_dist_kernel(const float *vecs, uint
     }
     uint32_t o = lane < W ? rows[(uint64_t)t * W + lane] : PH_EMPTY32;
     uint32_t vo = o < n ? nodes[o] : 0;
-    float myd = PH_FMAX;
-    uint64_t rem = __ballot(o < n);
-    while (rem) {
-      int j = __builtin_ctzll(rem);
-      rem &= rem - 1;
-      float p = wave_sum(row_partial<NV>((const float4 *)(vecs + (uint64_t)rl32(vo, j) * ld), qv, nv4, lane, l2));
-      if ((int)lane == j) myd = finalize_metric(p, metric);
-    }
+    float myd = batch_distances<NV>(vecs, ld, nv4, metric, l2, qv, __ballot(o < n), vo, lane);
+    if (!(o < n)) myd = PH_FMAX;
     if (lane < W) rows_d[(uint64_t)t * W + lane] = myd;
   }
 }

@@ -42,37 +42,80 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// one lane's share of Comparator::compare_raw: chunks lane, lane+64, ... in address order
-template <int NV>
-__device__ __forceinline__ float row_partial(const float4 *__restrict__ row, const float4 (&q)[NV],
-                                             uint32_t nv4, uint32_t lane, bool l2) {
-  float4 x[NV];
+// one lane's share of Comparator::compare_raw for U candidate rows at once: chunks lane,
+// lane+64, ... of each row in address order, ONE fma chain per row (the order the oracle's
+// ORC_SUM_BLOCKED64 restates).  All U*NV loads are issued before the first use so that U
+// rows are in flight per wave; out-of-range chunks (dim not a multiple of 256) load a
+// clamped address and are skipped in the accumulate by a select, not a branch.
+template <int NV, int U, bool EXACT, bool L2>
+__device__ __forceinline__ void rows_partial_impl(const float4 *const (&row)[U], const float4 (&q)[NV], uint32_t nv4,
+                                                  uint32_t lane, float (&acc)[U]) {
+  float4 x[U][NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    uint32_t c = lane + 64u * k;
-    if (c < nv4) x[k] = row[c];
-  }
-  float acc = 0.f;
+  for (int u = 0; u < U; u++) {
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    uint32_t c = lane + 64u * k;
-    if (c < nv4) {
-      if (l2) {
-        float d0 = q[k].x - x[k].x, d1 = q[k].y - x[k].y, d2 = q[k].z - x[k].z, d3 = q[k].w - x[k].w;
-        acc = fmaf(d0, d0, acc);
-        acc = fmaf(d1, d1, acc);
-        acc = fmaf(d2, d2, acc);
-        acc = fmaf(d3, d3, acc);
-      } else {
-        acc = fmaf(q[k].x, x[k].x, acc);
-        acc = fmaf(q[k].y, x[k].y, acc);
-        acc = fmaf(q[k].z, x[k].z, acc);
-        acc = fmaf(q[k].w, x[k].w, acc);
-      }
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      if (!EXACT) c = c < nv4 ? c : nv4 - 1;
+      x[u][k] = row[u][c];
     }
   }
-  return acc;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      float t = a;
+      if (L2) {
+        float d0 = q[k].x - x[u][k].x, d1 = q[k].y - x[u][k].y, d2 = q[k].z - x[u][k].z, d3 = q[k].w - x[u][k].w;
+        t = fmaf(d0, d0, t);
+        t = fmaf(d1, d1, t);
+        t = fmaf(d2, d2, t);
+        t = fmaf(d3, d3, t);
+      } else {
+        t = fmaf(q[k].x, x[u][k].x, t);
+        t = fmaf(q[k].y, x[u][k].y, t);
+        t = fmaf(q[k].z, x[u][k].z, t);
+        t = fmaf(q[k].w, x[u][k].w, t);
+      }
+      a = (EXACT || lane + 64u * k < nv4) ? t : a;
+    }
+    acc[u] = a;
+  }
 }
+
+template <int NV, int U>
+__device__ __forceinline__ void rows_partial(const float4 *const (&row)[U], const float4 (&q)[NV], uint32_t nv4,
+                                             uint32_t lane, bool l2, float (&acc)[U]) {
+  const bool exact = nv4 == 64u * NV;  // wave-uniform
+  if (exact) {
+    if (l2)
+      rows_partial_impl<NV, U, true, true>(row, q, nv4, lane, acc);
+    else
+      rows_partial_impl<NV, U, true, false>(row, q, nv4, lane, acc);
+  } else {
+    if (l2)
+      rows_partial_impl<NV, U, false, true>(row, q, nv4, lane, acc);
+    else
+      rows_partial_impl<NV, U, false, false>(row, q, nv4, lane, acc);
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ float row_partial(const float4 *__restrict__ row, const float4 (&q)[NV], uint32_t nv4,
+                                             uint32_t lane, bool l2) {
+  const float4 *const r[1] = {row};
+  float acc[1];
+  rows_partial<NV, 1>(r, q, nv4, lane, l2, acc);
+  return acc[0];
+}
+
+// distances of the query to the (up to 64) rows whose ids sit in the lanes flagged by
+// `mask`; 4 rows in flight; the result lands in the lane that held the id
+template <int NV>
+__device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
+                                                 bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
+                                                 uint32_t lane);
 
 __device__ __forceinline__ float finalize_metric(float r, int metric) {
   if (metric == PHNSW_METRIC_COSINE_HALF) return (1.0f - r) / 2.0f;  // bigvec.rs:52
@@ -97,3 +140,33 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *ids, const f
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+
+template <int NV>
+__device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
+                                                 bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
+                                                 uint32_t lane) {
+  float myd = 0.f;
+  uint64_t rem = mask;
+  while (rem) {
+    int l[4];
+    l[0] = __builtin_ctzll(rem);
+    rem &= rem - 1;
+#pragma unroll
+    for (int u = 1; u < 4; u++) {
+      l[u] = rem ? __builtin_ctzll(rem) : l[0];  // short tail: recompute row l[0] (same value)
+      rem &= rem ? rem - 1 : 0;
+    }
+    const float4 *r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) r[u] = (const float4 *)(vecs + (uint64_t)rl32(vid, l[u]) * ld);
+    const float4 *const rr[4] = {r[0], r[1], r[2], r[3]};
+    float p[4];
+    rows_partial<NV, 4>(rr, qv, nv4, lane, l2, p);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float d = finalize_metric(wave_sum(p[u]), metric);
+      if ((int)lane == l[u]) myd = d;
+    }
+  }
+  return myd;
+}

@@ -204,36 +204,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         if (fresh) vid = identity ? nb : L.nodes[nb];
 
         // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202
-        float myd = 0.f;
-        {
-          uint64_t rem = fm;
-          while (rem) {
-            int l0 = __builtin_ctzll(rem);
-            rem &= rem - 1;
-            int l1 = rem ? __builtin_ctzll(rem) : l0;
-            rem &= rem ? rem - 1 : 0;
-            int l2_ = rem ? __builtin_ctzll(rem) : l0;
-            rem &= rem ? rem - 1 : 0;
-            int l3 = rem ? __builtin_ctzll(rem) : l0;
-            rem &= rem ? rem - 1 : 0;
-            const float4 *r0 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l0) * a.ld);
-            const float4 *r1 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l1) * a.ld);
-            const float4 *r2 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l2_) * a.ld);
-            const float4 *r3 = (const float4 *)(a.vecs + (uint64_t)rl32(vid, l3) * a.ld);
-            float p0 = row_partial<NV>(r0, qv, nv4, lane, l2);
-            float p1 = row_partial<NV>(r1, qv, nv4, lane, l2);
-            float p2 = row_partial<NV>(r2, qv, nv4, lane, l2);
-            float p3 = row_partial<NV>(r3, qv, nv4, lane, l2);
-            p0 = wave_sum(p0);
-            p1 = wave_sum(p1);
-            p2 = wave_sum(p2);
-            p3 = wave_sum(p3);
-            if ((int)lane == l0) myd = finalize_metric(p0, a.metric);
-            if ((int)lane == l1) myd = finalize_metric(p1, a.metric);
-            if ((int)lane == l2_) myd = finalize_metric(p2, a.metric);
-            if ((int)lane == l3) myd = finalize_metric(p3, a.metric);
-          }
-        }
+        const float myd = batch_distances<NV>(a.vecs, a.ld, nv4, a.metric, l2, qv, fm, vid, lane);
 
         // candidates.merge_pairs(sorted batch)  lib.rs:206,226 / priority_queue.rs:109-144,
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
