@@ -158,7 +158,7 @@ def main():
             build_s, args.n / build_s, [index._layer(l).node_count() for l in range(index.layer_count())]))
         base_t = tensor_of(store)
         # calibration queries are the same on every rank => every rank picks the same parameters
-        cal = make_store(kind, 2000, 2 ** 33)
+        cal = make_store(kind, 8192, 2 ** 33)
         cal_gt = ground_truth(base_t, tensor_of(cal))
         cal_run = Runner(index, cal)
         if args.ef:
