@@ -220,6 +220,24 @@ int phnsw_link_apply_device(phnsw_index *ix, uint32_t layer_from_top, uint64_t l
 int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
                       uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection);
 
+/* ---- product quantisation (reference src/pq.rs; BASELINE config 5) ----
+ * A PQ store holds u8 code rows [n][m] over per-sub-space codebooks [m][ksub][dim/m]
+ * (random_centroids pq.rs:261-285 per sub-space; Quantizer::quantize pq.rs:61-71 as the exact
+ * nearest centroid).  It is a phnsw_store: phnsw_build / phnsw_search_batch / phnsw_link_layer
+ * ... run on it with quantised distances (a per-query lookup table in LDS; a Stored query is its
+ * reconstruction, so code-vs-code distances are symmetric).  m % 4 == 0, dim % m == 0,
+ * ksub <= 256, m*ksub*4 bytes must fit the LDS. */
+int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out);
+int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);
+int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook);
+/* QuantizedHnsw::search  pq.rs:346-364 for a batch: search the index over the PQ store, re-rank
+ * every result with the full-precision store, sort by (distance, id).  quantize_query != 0
+ * quantises the query first like the reference (pq.rs:351-352); 0 = asymmetric (raw query
+ * against codes).  Outputs as phnsw_search_batch. */
+int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *full, const float *queries, uint64_t nq,
+                          const phnsw_search_params *sp, int quantize_query, uint64_t *out_ids,
+                          float *out_d, uint64_t *out_len, uint64_t *out_stats);
+
 /* Hnsw::knn  src/lib.rs:905-928 : bottom layer, out [node_count][k] */
 int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
               float *out_d, uint64_t *out_len);

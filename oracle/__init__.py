@@ -48,7 +48,8 @@ class BuildParams(C.Structure):
 
 class Store(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("n", C.c_uint64), ("dim", C.c_uint32), ("ld", C.c_uint32),
-                ("metric", C.c_int), ("sum_mode", C.c_int)]
+                ("metric", C.c_int), ("sum_mode", C.c_int), ("codes", C.c_void_p), ("codebook", C.c_void_p),
+                ("pq_m", C.c_uint32), ("pq_ksub", C.c_uint32), ("pq_dsub", C.c_uint32)]
 
 
 class LayerS(C.Structure):
@@ -140,6 +141,11 @@ def lib():
         L.orc_shuffle_u64.argtypes = [vp, u64, u64]
         L.orc_synth_rows.argtypes = [vp, u64, u64, u32, u32, u64, i32, i32]
         L.orc_synth_clustered_rows.argtypes = [vp, u64, u64, u32, u32, u64, u32, f32, i32]
+        L.orc_pq_create.restype = i32
+        L.orc_pq_create.argtypes = [vp, u64, u32, u32, u32, u32, u64, vp, vp, i32]
+        L.orc_index_set_pq.argtypes = [vp, vp, vp, u32, u32, u32]
+        L.orc_pq_search_batch.restype = i32
+        L.orc_pq_search_batch.argtypes = [vp, C.POINTER(Store), vp, u32, u64, SearchParams, i32, vp, vp, vp, vp, i32]
         L.orc_feistel_perm.restype = u64
         L.orc_feistel_perm.argtypes = [u64, u64, u64]
         _lib = L
@@ -234,6 +240,18 @@ def synth_clustered_rows(first, count, dim, seed=42, n_clusters=1000, noise=1.0,
     return rows
 
 
+def pq_create(rows, dim, m, ksub, seed=0, threads=8):
+    """codes [n, m] u8 and codebook [m, ksub, dim/m] (orc_pq_create)"""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n, ld = rows.shape
+    codes = np.zeros((n, m), dtype=np.uint8)
+    codebook = np.zeros((m, ksub, dim // m), dtype=np.float32)
+    rc = lib().orc_pq_create(_p(rows), n, dim, ld, m, ksub, seed, _p(codes), _p(codebook), threads)
+    if rc:
+        raise RuntimeError("orc_pq_create rc=%d" % rc)
+    return codes, codebook
+
+
 def shuffle(ids, seed):
     v = np.array(ids, dtype=np.uint64)
     lib().orc_shuffle_u64(_p(v), len(v), seed)
@@ -261,7 +279,7 @@ class Index:
 
     def store(self, sum_mode=None):
         return Store(_p(self.rows), self.rows.shape[0], self.dim, self.ld, self.metric,
-                     self._sum_mode if sum_mode is None else sum_mode)
+                     self._sum_mode if sum_mode is None else sum_mode, None, None, 0, 0, 0)
 
     _sum_mode = SUM_SEQ
 
@@ -381,6 +399,31 @@ class Index:
 
     def improve_index(self, bp, threads=8):
         return lib().orc_improve_index(self.h, C.byref(bp), threads)
+
+    # -- product quantisation (pq.rs) --
+    def set_pq(self, codes, codebook):
+        """turn this index's store into a PQ store over the given codes / codebooks"""
+        self.pq_codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.pq_codebook = np.ascontiguousarray(codebook, dtype=np.float32)
+        m, ksub, dsub = self.pq_codebook.shape
+        assert self.pq_codes.shape == (self.rows.shape[0], m)
+        lib().orc_index_set_pq(self.h, _p(self.pq_codes), _p(self.pq_codebook), m, ksub, dsub)
+
+    def pq_search(self, full, queries, sp, quantize_query=False, threads=8, stats=False):
+        """QuantizedHnsw::search: `full` is an Index over the f32 rows (its sum mode is used)"""
+        sp = SearchParams(*sp)
+        q, _, ldq = pad_rows(np.atleast_2d(queries))
+        nq, cap = q.shape[0], sp.number_of_candidates
+        ids = np.empty((nq, cap), dtype=np.uint64)
+        d = np.empty((nq, cap), dtype=np.float32)
+        ln = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros((nq, 2), dtype=np.uint64)
+        fs = full.store()
+        rc = lib().orc_pq_search_batch(self.h, C.byref(fs), _p(q), ldq, nq, sp, int(quantize_query), _p(ids), _p(d),
+                                       _p(ln), _p(st), threads)
+        if rc:
+            raise RuntimeError("orc_pq_search_batch rc=%d" % rc)
+        return (ids, d, ln, st) if stats else (ids, d, ln)
 
     def check_layer_invariants(self):
         return lib().orc_check_layer_invariants(self.h)

@@ -50,6 +50,11 @@ typedef struct {
   uint32_t ld;
   int metric;
   int sum_mode;
+  /* product-quantised store (pq.rs): when codes != NULL the rows of the store are u8 code rows
+   * [n][pq_m] over per-sub-space codebooks [pq_m][pq_ksub][pq_dsub]; queries stay f32 */
+  const uint8_t *codes;
+  const float *codebook;
+  uint32_t pq_m, pq_ksub, pq_dsub;
 } orc_store;
 
 float orc_distance(const orc_store *s, const float *a, const float *b);
@@ -195,6 +200,21 @@ void orc_synth_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, u
                     uint64_t seed, int normalize, int threads);
 void orc_synth_clustered_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                               uint64_t seed, uint32_t n_clusters, float noise, int threads);
+/* ---- product quantisation (pq.rs; per-sub-space codebooks, u8 codes: BASELINE config 5) ---- */
+/* random_centroids (pq.rs:261-285) per sub-space + Quantizer::quantize (pq.rs:61-71, exact
+ * nearest centroid) for every row; codes [n][m], codebook [m][ksub][dim/m] */
+int orc_pq_create(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub,
+                  uint64_t seed, uint8_t *codes, float *codebook, int threads);
+void orc_pq_encode(const float *rows, uint64_t n, uint32_t ld, uint32_t m, uint32_t ksub, uint32_t dsub,
+                   const float *codebook, uint8_t *codes, int threads);
+/* turn the index's store into a PQ store (the arrays must outlive the index) */
+void orc_index_set_pq(orc_index *ix, const uint8_t *codes, const float *codebook, uint32_t m, uint32_t ksub,
+                      uint32_t dsub);
+/* QuantizedHnsw::search pq.rs:346-364: search the code graph, re-rank with the full store
+ * (sum_mode of `full`), sort (d, id) */
+int orc_pq_search_batch(const orc_index *ix, const orc_store *full, const float *queries, uint32_t ldq,
+                        uint64_t nq, orc_search_params sp, int quantize_query, uint64_t *out_ids, float *out_d,
+                        uint64_t *out_len, orc_stats *st, int threads);
 /* format-preserving permutation of [0,domain) used by the neighbour seeding step */
 uint64_t orc_feistel_perm(uint64_t i, uint64_t domain, uint64_t key);
 

@@ -242,6 +242,7 @@ int orc_layer_init_search(orc_index *ix, const orc_build_params *bp, uint64_t fi
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_scratch *sc = layer_count ? orc_scratch_new(ix, 0) : NULL;
+    orc_scratch *sc0 = orc_scratch_new(ix, 0);
     uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * (ips.number_of_candidates + 1));
     float *od = (float *)malloc(sizeof(float) * (ips.number_of_candidates + 1));
     nd_pair *tmp = (nd_pair *)malloc(sizeof(nd_pair) * (K + 1));
@@ -251,9 +252,10 @@ int orc_layer_init_search(orc_index *ix, const orc_build_params *bp, uint64_t fi
       uint64_t m = 0;
       if (layer_count == 0) {
         /* compare_all  src/search.rs:13-30 */
+        orc_query_prepare(S, sc0, NULL, vs[i]);
         for (uint64_t j = 0; j < n; j++) {
           if (vs[j] == vs[i]) continue;
-          nd_pair p = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[j] * (uint64_t)S->ld), j};
+          nd_pair p = {orc_query_dist(S, sc0, vs[j]), j};
           tmp[m++] = p;
         }
         qsort(tmp, m, sizeof(nd_pair), nd_cmp); /* ids are node ids; monotone in vector id */
@@ -293,6 +295,7 @@ int orc_layer_init_search(orc_index *ix, const orc_build_params *bp, uint64_t fi
     free(od);
     free(tmp);
     orc_scratch_free(sc);
+    orc_scratch_free(sc0);
   }
   return rc_all;
 }
@@ -342,6 +345,7 @@ int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *in
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     uint64_t maxc = W * 5 + K + 8;
+    orc_scratch *sc = orc_scratch_new(ix, 0);
     nd_pair *list = (nd_pair *)malloc(sizeof(nd_pair) * maxc);
     uint64_t *pstart = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
     uint64_t *psize = (uint64_t *)malloc(sizeof(uint64_t) * (K + 1));
@@ -379,6 +383,7 @@ int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *in
       uint64_t picks = choice_count < domain ? choice_count : domain;
       /* StdRng::seed_from_u64(layer_count + vector_id + vs.len())  :729-731 */
       uint64_t key = orc_mix64((uint64_t)layer_count + vs[i] + n) ^ orc_mix64(bp->seed + 0x632BE59BD9B4E019ULL);
+      orc_query_prepare(S, sc, NULL, vs[i]);
       for (uint64_t k = 0; k < picks; k++) {
         uint64_t f = orc_feistel_perm(k, domain, key);
         if (excl && f >= i) f += 1;
@@ -389,7 +394,7 @@ int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *in
         }
         uint64_t member = gmem[pstart[p] + f];
         /* compare_vec(Stored(vector_id), Stored(choice.1))  :750-754 */
-        nd_pair c = {orc_distance(S, S->rows + vs[i] * (uint64_t)S->ld, S->rows + vs[member] * (uint64_t)S->ld), member};
+        nd_pair c = {orc_query_dist(S, sc, vs[member]), member};
         list[m++] = c;
       }
       finish_row(list, m, i, W, out_rows + x * W, out_rows_d + x * W);
@@ -397,6 +402,7 @@ int orc_layer_seed(orc_index *ix, const orc_build_params *bp, const uint64_t *in
     free(list);
     free(pstart);
     free(psize);
+    orc_scratch_free(sc);
   }
   return 0;
 }
@@ -493,14 +499,19 @@ uint64_t orc_link_apply(orc_index *ix, uint32_t lft, uint64_t link_count, const 
   int T = threads > 0 ? threads : 1;
   /* distances of the current occupants to the row owner, recomputed as :1128-1133 does */
   float *rows_d = (float *)malloc(sizeof(float) * n * W);
-#pragma omp parallel for num_threads(T) schedule(dynamic, 64)
-  for (uint64_t t = 0; t < n; t++)
-    for (uint64_t k = 0; k < W; k++) {
-      uint64_t o = L->neighbors[t * W + k];
-      rows_d[t * W + k] = o == ORC_EMPTY ? ORC_FMAX
-                                         : orc_distance(S, S->rows + L->nodes[o] * (uint64_t)S->ld,
-                                                        S->rows + L->nodes[t] * (uint64_t)S->ld);
+#pragma omp parallel num_threads(T)
+  {
+    orc_scratch *sc = orc_scratch_new(ix, 0);
+#pragma omp for schedule(dynamic, 64)
+    for (uint64_t t = 0; t < n; t++) {
+      orc_query_prepare(S, sc, NULL, L->nodes[t]); /* the metrics are symmetric bit for bit */
+      for (uint64_t k = 0; k < W; k++) {
+        uint64_t o = L->neighbors[t * W + k];
+        rows_d[t * W + k] = o == ORC_EMPTY ? ORC_FMAX : orc_query_dist(S, sc, L->nodes[o]);
+      }
     }
+    orc_scratch_free(sc);
+  }
   uint64_t *ft = (uint64_t *)malloc(sizeof(uint64_t) * (n * link_count + 1));
   uint64_t *fs = (uint64_t *)malloc(sizeof(uint64_t) * (n * link_count + 1));
   float *fd = (float *)malloc(sizeof(float) * (n * link_count + 1));

@@ -41,13 +41,22 @@ typedef struct {
   uint64_t *p_ids;
   float *p_d;
   uint64_t p_cap;
+  /* the prepared query: f32 vector, or (PQ store) its lookup table T[m][ksub] */
+  const float *qv;
+  float *pq_table;
+  float *pq_recon;
 } orc_scratch;
+
+/* lookup_abstract + the start of compare_vec (lib.rs:60-73): fix the query side once */
+void orc_query_prepare(const orc_store *S, orc_scratch *sc, const float *raw, uint64_t stored_id);
+/* compare_vec(query, Stored(vid)) */
+float orc_query_dist(const orc_store *S, const orc_scratch *sc, uint64_t vid);
 
 orc_scratch *orc_scratch_new(const orc_index *ix, uint64_t extra_nodes);
 void orc_scratch_free(orc_scratch *sc);
 uint64_t orc_layer_get_node(const orc_layer *L, uint64_t v);
-uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, const float *qv, orc_pq *cand,
-                           uint64_t probe_depth, orc_scratch *sc, orc_stats *st);
+uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, orc_pq *cand, uint64_t probe_depth,
+                           orc_scratch *sc, orc_stats *st);
 int orc_search_sc(const orc_index *ix, const float *query, uint64_t qid, orc_search_params sp,
                   uint32_t upto_layers, uint64_t exclude, uint64_t *out_ids, float *out_d,
                   uint64_t *out_len, orc_stats *st, orc_scratch *sc, uint64_t *index_distance);

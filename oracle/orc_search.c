@@ -19,6 +19,8 @@ orc_index *orc_index_new(const float *rows, uint64_t n, uint32_t dim, uint32_t l
   ix->store.ld = ld;
   ix->store.metric = metric;
   ix->store.sum_mode = sum_mode;
+  ix->store.codes = NULL;
+  ix->store.codebook = NULL;
   return ix;
 }
 
@@ -109,6 +111,8 @@ void orc_scratch_free(orc_scratch *sc) {
   free(sc->c_d);
   free(sc->p_ids);
   free(sc->p_d);
+  free(sc->pq_table);
+  free(sc->pq_recon);
   free(sc);
 }
 
@@ -187,8 +191,8 @@ static void sort_pairs(uint64_t *ids, float *d, uint64_t m) {
 
 /* Layer::closest_nodes  src/lib.rs:175-248.  qv = the query vector (lookup_abstract of
  * Stored/Unstored already resolved, src/lib.rs:60-73). */
-uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, const float *qv, orc_pq *cand,
-                           uint64_t probe_depth, orc_scratch *sc, orc_stats *st) {
+uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, orc_pq *cand, uint64_t probe_depth,
+                           orc_scratch *sc, orc_stats *st) {
   const orc_store *S = &ix->store;
   /* assert!(!candidates.is_empty())  :175 */
   sc->epoch++;
@@ -219,7 +223,7 @@ uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, const float 
       uint64_t n = L->neighbors[k];
       if (sc->visited[n] == sc->epoch) continue; /* filter(!visited.contains) :198 */
       /* compare_vec(v, Stored(get_vector(n)))  :200-202 */
-      float d = orc_distance(S, qv, S->rows + L->nodes[n] * (uint64_t)S->ld);
+      float d = orc_query_dist(S, sc, L->nodes[n]);
       if (st) st->n_dist++;
       sc->batch_ids[m] = n;
       sc->batch_d[m] = d;
@@ -252,8 +256,7 @@ uint64_t orc_closest_nodes(const orc_index *ix, const orc_layer *L, const float 
 
 /* Layer::closest_vectors  src/lib.rs:250-277.  cand holds VectorIds; result pairs are
  * written to sc->p_* (VectorIds), returns count or -1 when get_node().unwrap() would panic */
-static int64_t closest_vectors(const orc_index *ix, const orc_layer *L, const float *qv,
-                               const orc_pq *cand, uint64_t candidate_count, uint64_t probe_depth,
+static int64_t closest_vectors(const orc_index *ix, const orc_layer *L, const orc_pq *cand, uint64_t candidate_count, uint64_t probe_depth,
                                uint64_t exclude, orc_scratch *sc, orc_stats *st,
                                uint64_t *index_distance) {
   uint64_t cap = cand->cap; /* PriorityQueue::new(candidates.capacity())  :264 */
@@ -272,7 +275,7 @@ static int64_t closest_vectors(const orc_index *ix, const orc_layer *L, const fl
     queue.prio[i] = ORC_FMAX;
   }
   orc_pq_merge(&queue, sc->p_ids, sc->p_d, np);                                 /* :266 */
-  *index_distance = orc_closest_nodes(ix, L, qv, &queue, probe_depth, sc, st); /* :267 */
+  *index_distance = orc_closest_nodes(ix, L, &queue, probe_depth, sc, st); /* :267 */
   uint64_t nq = orc_pq_iter_len(&queue);
   uint64_t out = 0;
   for (uint64_t i = 0; i < nq && out < candidate_count; i++) { /* :269-275 */
@@ -294,7 +297,7 @@ int orc_search_sc(const orc_index *ix, const float *query, uint64_t qid, orc_sea
   const orc_store *S = &ix->store;
   uint32_t nl = (upto_layers == 0 || upto_layers > ix->layer_count) ? ix->layer_count : upto_layers;
   if (nl == 0 || sp.number_of_candidates == 0 || sp.probe_depth == 0) return -3;
-  const float *qv = query ? query : S->rows + qid * (uint64_t)S->ld;
+  orc_query_prepare(S, sc, query, qid);
   const orc_layer *layers = ix->layers;
   uint64_t cap = sp.number_of_candidates;
   ensure_pairs(&sc->c_ids, &sc->c_d, &sc->c_cap, cap);
@@ -304,14 +307,14 @@ int orc_search_sc(const orc_index *ix, const float *query, uint64_t qid, orc_sea
     cand.prio[i] = ORC_FMAX;
   }
   uint64_t entry = layers[0].nodes[0]; /* entry_vector  src/search.rs:9-11 */
-  float d0 = orc_distance(S, qv, S->rows + entry * (uint64_t)S->ld); /* :102-109 */
+  float d0 = orc_query_dist(S, sc, entry); /* :102-109 */
   if (st) st->n_dist++;
   orc_pq_insert(&cand, entry, d0); /* :111 */
   uint64_t last_index_distance = UINT64_MAX;
   for (uint32_t i = 0; i < nl; i++) { /* :113 */
     uint64_t candidate_count = (nl == 1 || i == nl - 1) ? sp.number_of_candidates
                                                         : sp.upper_layer_candidate_count; /* :122-126 */
-    int64_t n = closest_vectors(ix, &layers[i], qv, &cand, candidate_count, sp.probe_depth, exclude,
+    int64_t n = closest_vectors(ix, &layers[i], &cand, candidate_count, sp.probe_depth, exclude,
                                 sc, st, &last_index_distance); /* :128-134 */
     if (n < 0) return -2;
     orc_pq_merge(&cand, sc->p_ids, sc->p_d, (uint64_t)n); /* :136 */
@@ -388,7 +391,8 @@ int orc_knn(const orc_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out
       uint64_t self = i;
       float zero = 0.0f;
       orc_pq_merge(&pq, &self, &zero, 1); /* pq.merge_pairs(&[(node, 0.0)]) */
-      orc_closest_nodes(ix, L, S->rows + L->nodes[i] * (uint64_t)S->ld, &pq, probe_depth, sc, NULL);
+      orc_query_prepare(S, sc, NULL, L->nodes[i]);
+      orc_closest_nodes(ix, L, &pq, probe_depth, sc, NULL);
       uint64_t n = orc_pq_iter_len(&pq), out = 0;
       for (uint64_t j = 0; j < n && out < k; j++) {
         if (ids[j] == self) continue;
@@ -437,7 +441,8 @@ int orc_threshold_nn(const orc_index *ix, float threshold, uint64_t probe_depth,
       uint64_t last_size = 0;
       while (last < threshold && orc_pq_len(&pq) > last_size) {
         last_size = orc_pq_len(&pq);
-        orc_closest_nodes(ix, L, S->rows + L->nodes[i] * (uint64_t)S->ld, &pq, probe_depth, sc, NULL);
+        orc_query_prepare(S, sc, NULL, L->nodes[i]);
+        orc_closest_nodes(ix, L, &pq, probe_depth, sc, NULL);
         uint64_t len = orc_pq_len(&pq);
         last = pq.prio[len - 1]; /* pq.last().expect(..).1 */
         if (last < threshold && len == pq.cap) {

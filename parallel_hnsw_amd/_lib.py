@@ -82,6 +82,10 @@ SYMBOLS = {
     "phnsw_link_apply_device": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
     "phnsw_recall_hits": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), _u64, _u64, C.POINTER(_u64),
                                  C.POINTER(_u64)]),
+    "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),
+    "phnsw_pq_info": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "phnsw_pq_read": (_i32, [_vp, _vp, _vp]),
+    "phnsw_pq_search_batch": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(SearchParams), _i32, _vp, _vp, _vp, _vp]),
     "phnsw_knn": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
 }
 

@@ -236,8 +236,8 @@ extern "C" int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim
 }
 
 extern "C" int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t count, float *out) {
-  if (!s || !out || first + count > s->n) {
-    ph_set_error("phnsw_store_read: range out of bounds");
+  if (!s || !out || !s->rows || first + count > s->n) {
+    ph_set_error("phnsw_store_read: range out of bounds (or a product-quantised store: use phnsw_pq_read)");
     return PHNSW_E_INVALID;
   }
   PH_HIP(hipSetDevice(s->device));
@@ -252,6 +252,8 @@ extern "C" void phnsw_store_destroy(phnsw_store *s) {
   if (--s->refcount > 0) return;
   hipSetDevice(s->device);
   if (s->owns_rows && s->rows) hipFree(s->rows);
+  if (s->codes) hipFree(s->codes);
+  if (s->codebook) hipFree(s->codebook);
   delete s;
 }
 
@@ -278,14 +280,13 @@ extern "C" int phnsw_distance_batch(const phnsw_store *s, const float *query, ui
     e = hipMemcpy(qd, qpad.data(), (size_t)s->ld * 4, hipMemcpyHostToDevice);
     qsrc = qd;
   } else {
-    qsrc = s->rows + query_id * s->ld;
     e = hipSuccess;
   }
   if (e == hipSuccess) e = hipMalloc(&idd, k * 4);
   if (e == hipSuccess) e = hipMalloc(&od, k * 4);
   if (e == hipSuccess) e = hipMemcpy(idd, ids32.data(), k * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) rc = ph_hip_fail(e, "distance_batch setup", __FILE__, __LINE__);
-  if (!rc) rc = ph_distance_batch(s, qsrc, idd, (uint32_t)k, od, 0);
+  if (!rc) rc = ph_distance_batch(s, qsrc, (uint32_t)query_id, idd, (uint32_t)k, od, 0);
   if (!rc) {
     e = hipMemcpy(out, od, k * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = ph_hip_fail(e, "distance_batch copy", __FILE__, __LINE__);
@@ -480,10 +481,7 @@ static int check_sp(const phnsw_index *ix, const phnsw_search_params *sp) {
 static void fill_args(const phnsw_index *ix, const phnsw_search_params *sp, uint32_t upto, PhSearchArgs &a) {
   memset(&a, 0, sizeof(a));
   const phnsw_store *s = ix->store;
-  a.vecs = s->rows;
-  a.ld = s->ld;
-  a.nv4 = s->ld / 4;
-  a.metric = s->metric;
+  a.dist = ph_dist_args(s);
   uint32_t nl = (upto == 0 || upto > ix->layers.size()) ? (uint32_t)ix->layers.size() : upto;
   a.n_layers = nl;
   for (uint32_t l = 0; l < nl; l++) {

@@ -139,9 +139,7 @@ __global__ void ph_init_from_search_kernel(const uint32_t *nodes, uint32_t count
 }
 
 struct PhSeedArgs {
-  const float *vecs;
-  uint32_t ld, nv4;
-  int metric;
+  PhDistArgs dist;
   const uint32_t *nodes;  // NodeId -> VectorId of the layer being built
   uint32_t n, W, K;
   const uint32_t *init_ids;
@@ -161,21 +159,17 @@ struct PhSeedArgs {
 
 // K3: one wave per node: candidates = supers U picks from the supers' partitions, a
 // distance batch, then sort (d,id) / dedup / drop self / take W  (lib.rs:719-787)
-template <int NV>
+template <class Dist>
 __global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
   __shared__ uint64_t keys[SEED_CMAX];
   __shared__ uint64_t sorted[SEED_CMAX];
+  extern __shared__ float dist_lds[];  // DistPQ table
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
-  const bool l2 = a.metric == PHNSW_METRIC_L2;
   for (uint32_t i = a.first + blockIdx.x; i < a.first + a.count; i += gridDim.x) {
     const uint32_t self_vec = a.nodes[i];
-    float4 qv[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      uint32_t c = lane + 64u * k;
-      qv[k] = (c < a.nv4) ? ((const float4 *)(a.vecs + (uint64_t)self_vec * a.ld))[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    Dist dist;
+    dist.prepare_stored(a.dist, self_vec, dist_lds, lane);
     const uint32_t len = a.init_len[i];
     uint32_t sid = 0;
     float sd = 0.f;
@@ -242,7 +236,7 @@ __global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
         // keep the readlane loop wave-uniform: inactive lanes still run it (nothing to do)
       }
       // compare_vec(Stored(vector_id), Stored(choice.1))  lib.rs:750-754
-      const float myd = batch_distances<NV>(a.vecs, a.ld, a.nv4, a.metric, l2, qv, __ballot(act), vm, lane);
+      const float myd = dist.batch(a.dist, __ballot(act), vm, lane);
       if (act) keys[len + k] = mkkey(myd, member);
     }
     __syncthreads();
@@ -406,25 +400,20 @@ __global__ __launch_bounds__(64) void ph_merge_rows_kernel(uint32_t n, uint32_t 
 
 // distance of every occupant to its row owner (the values lib.rs:1128-1133 recomputes);
 // one wave per row
-template <int NV>
-__global__ __launch_bounds__(64) void ph_row_dist_kernel(const float *vecs, uint32_t ld, uint32_t nv4, int metric,
-                                                         const uint32_t *nodes, uint32_t n, uint32_t W,
+template <class Dist>
+__global__ __launch_bounds__(64) void ph_row_dist_kernel(PhDistArgs da, const uint32_t *nodes, uint32_t n, uint32_t W,
                                                          const uint32_t *rows, float *rows_d) {
+  extern __shared__ float dist_lds[];
   const uint32_t lane = threadIdx.x;
-  const bool l2 = metric == PHNSW_METRIC_L2;
   for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
-    float4 qv[NV];
-    const float4 *qrow = (const float4 *)(vecs + (uint64_t)nodes[t] * ld);
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      uint32_t c = lane + 64u * k;
-      qv[k] = (c < nv4) ? qrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    Dist dist;
+    dist.prepare_stored(da, nodes[t], dist_lds, lane);
     uint32_t o = lane < W ? rows[(uint64_t)t * W + lane] : PH_EMPTY32;
     uint32_t vo = o < n ? nodes[o] : 0;
-    float myd = batch_distances<NV>(vecs, ld, nv4, metric, l2, qv, __ballot(o < n), vo, lane);
+    float myd = dist.batch(da, __ballot(o < n), vo, lane);
     if (!(o < n)) myd = PH_FMAX;
     if (lane < W) rows_d[(uint64_t)t * W + lane] = myd;
+    __syncthreads();
   }
 }
 
@@ -452,6 +441,36 @@ __global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const 
 // ------------------------------------------------------------------ host: shared steps
 
 static int nv_for(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
+static bool store_supported(const phnsw_store *s) { return s->codes ? true : nv_for(s->ld / 4) != 0; }
+
+template <typename K1, typename K3, typename K6, typename KQ, typename... Args>
+static int launch_by_policy(const phnsw_store *s, dim3 g, K1 k1, K3 k3, K6 k6, KQ kq, Args... args) {
+  if (s->codes) {
+    size_t lds = ph_pq_lds_bytes(s);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return ph_hip_fail(e, "hipFuncSetAttribute(LDS)", __FILE__, __LINE__);
+    }
+    hipLaunchKernelGGL(kq, g, dim3(64), lds, 0, args...);
+  } else {
+    switch (nv_for(s->ld / 4)) {
+      case 1:
+        hipLaunchKernelGGL(k1, g, dim3(64), 0, 0, args...);
+        break;
+      case 3:
+        hipLaunchKernelGGL(k3, g, dim3(64), 0, 0, args...);
+        break;
+      case 6:
+        hipLaunchKernelGGL(k6, g, dim3(64), 0, 0, args...);
+        break;
+      default:
+        ph_set_error("dim %u unsupported (max 1536)", s->dim);
+        return PHNSW_E_UNSUPPORTED;
+    }
+  }
+  PH_HIP(hipGetLastError());
+  return 0;
+}
 
 static uint32_t wave_grid(uint32_t n) {
   return std::min<uint32_t>(n, 256u * 32u);
@@ -494,27 +513,11 @@ static int ensure_row_dist(phnsw_index *ix, PhLayerHost &L) {
   if (L.nbr_dist) return 0;
   const phnsw_store *s = ix->store;
   PH_HIP(hipMalloc(&L.nbr_dist, (size_t)L.n_nodes * L.W * 4));
-  uint32_t nv4 = s->ld / 4;
-  dim3 g(wave_grid(L.n_nodes)), b(64);
-  switch (nv_for(nv4)) {
-    case 1:
-      hipLaunchKernelGGL(ph_row_dist_kernel<1>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
-                         L.neighbors, L.nbr_dist);
-      break;
-    case 3:
-      hipLaunchKernelGGL(ph_row_dist_kernel<3>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
-                         L.neighbors, L.nbr_dist);
-      break;
-    case 6:
-      hipLaunchKernelGGL(ph_row_dist_kernel<6>, g, b, 0, 0, s->rows, s->ld, nv4, s->metric, L.nodes, L.n_nodes, L.W,
-                         L.neighbors, L.nbr_dist);
-      break;
-    default:
-      ph_set_error("dim %u unsupported (max 1536)", s->dim);
-      return PHNSW_E_UNSUPPORTED;
-  }
-  PH_HIP(hipGetLastError());
-  return 0;
+  // a PQ table takes most of a CU's LDS: one resident wave per CU is all that fits
+  dim3 g(s->codes ? std::min<uint32_t>(L.n_nodes, 256u) : wave_grid(L.n_nodes));
+  return launch_by_policy(s, g, ph_row_dist_kernel<DistF32<1>>, ph_row_dist_kernel<DistF32<3>>,
+                          ph_row_dist_kernel<DistF32<6>>, ph_row_dist_kernel<DistPQ>, ph_dist_args(s), L.nodes, L.n_nodes,
+                          L.W, L.neighbors, L.nbr_dist);
 }
 
 // run the batched search for Stored queries and surface per-query failures
@@ -611,7 +614,7 @@ static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &no
   PH_TRY(out.alloc((size_t)n * n));
   PH_HIP(hipMemcpy(ids.p, nodes.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   for (uint32_t i = 0; i < n; i++)
-    PH_TRY(ph_distance_batch(s, s->rows + (uint64_t)nodes[i] * s->ld, ids.p, n, out.p + (size_t)i * n, 0));
+    PH_TRY(ph_distance_batch(s, nullptr, nodes[i], ids.p, n, out.p + (size_t)i * n, 0));
   std::vector<float> D((size_t)n * n);
   PH_HIP(hipMemcpy(D.data(), out.p, D.size() * 4, hipMemcpyDeviceToHost));
   std::vector<std::vector<HostPair>> init(n);
@@ -700,7 +703,7 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
     ph_set_error("generate_layer: more than %d layers", PH_MAX_LAYERS);
     return PHNSW_E_UNSUPPORTED;
   }
-  if (nv_for(s->ld / 4) == 0) {
+  if (!store_supported(s)) {
     ph_set_error("dim %u unsupported (max 1536)", s->dim);
     return PHNSW_E_UNSUPPORTED;
   }
@@ -830,10 +833,7 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   }
   if (count == 0) return 0;
   PhSeedArgs a;
-  a.vecs = s->rows;
-  a.ld = s->ld;
-  a.nv4 = s->ld / 4;
-  a.metric = s->metric;
+  a.dist = ph_dist_args(s);
   a.nodes = P->L.nodes;
   a.n = n;
   a.W = W;
@@ -850,19 +850,9 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   a.count = count;
   a.rows = out_rows;
   a.rows_d = out_rows_d;
-  dim3 g(wave_grid(count)), b(64);
-  switch (nv_for(a.nv4)) {
-    case 1:
-      hipLaunchKernelGGL(ph_seed_rows_kernel<1>, g, b, 0, 0, a);
-      break;
-    case 3:
-      hipLaunchKernelGGL(ph_seed_rows_kernel<3>, g, b, 0, 0, a);
-      break;
-    default:
-      hipLaunchKernelGGL(ph_seed_rows_kernel<6>, g, b, 0, 0, a);
-      break;
-  }
-  PH_HIP(hipGetLastError());
+  dim3 g(s->codes ? std::min<uint32_t>(count, 256u) : wave_grid(count));
+  PH_TRY(launch_by_policy(s, g, ph_seed_rows_kernel<DistF32<1>>, ph_seed_rows_kernel<DistF32<3>>,
+                          ph_seed_rows_kernel<DistF32<6>>, ph_seed_rows_kernel<DistPQ>, a));
   PH_HIP(hipDeviceSynchronize());
   return 0;
 }

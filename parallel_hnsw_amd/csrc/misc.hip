@@ -5,53 +5,57 @@
 
 #include "phnsw_device.h"
 
-// ---- K1: out[i] = compare_vec(query, Stored(ids[i])); one wave per candidate row ----
-template <int NV>
-__global__ __launch_bounds__(256) void ph_distance_batch_kernel(const float *__restrict__ vecs, uint32_t ld,
-                                                                uint32_t nv4, int metric,
-                                                                const float *__restrict__ query,
-                                                                const uint32_t *__restrict__ ids, uint32_t k,
-                                                                uint64_t n_store, float *__restrict__ out) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  float4 qv[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-    uint32_t c = lane + 64u * j;
-    qv[j] = (c < nv4) ? ((const float4 *)query)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const bool l2 = metric == PHNSW_METRIC_L2;
-  for (uint32_t i = wave; i < k; i += nwaves) {
-    uint32_t id = ids[i];
-    float d = PH_FMAX;
-    if (id < n_store) {
-      float r = wave_sum(row_partial<NV>((const float4 *)(vecs + (uint64_t)id * ld), qv, nv4, lane, l2));
-      d = finalize_metric(r, metric);
-    }
-    if (lane == 0) out[i] = d;
+// ---- K1: out[i] = compare_vec(query, Stored(ids[i])); a wave takes 64 candidates at a time ----
+template <class Dist>
+__global__ __launch_bounds__(64) void ph_distance_batch_kernel(PhDistArgs da, const float *__restrict__ query,
+                                                               uint32_t query_id, const uint32_t *__restrict__ ids,
+                                                               uint32_t k, uint64_t n_store, float *__restrict__ out) {
+  extern __shared__ float dist_lds[];
+  const uint32_t lane = threadIdx.x;
+  Dist dist;
+  if (query)
+    dist.prepare_raw(da, query, dist_lds, lane);
+  else
+    dist.prepare_stored(da, query_id, dist_lds, lane);
+  for (uint32_t base = blockIdx.x * 64u; base < k; base += gridDim.x * 64u) {
+    uint32_t i = base + lane;
+    uint32_t id = i < k ? ids[i] : PH_EMPTY32;
+    bool ok = id < n_store;
+    float d = dist.batch(da, __ballot(ok), ok ? id : 0u, lane);
+    if (i < k) out[i] = ok ? d : PH_FMAX;
   }
 }
 
-int ph_distance_batch(const phnsw_store *st, const float *q_dev, const uint32_t *ids_dev, uint32_t k,
+int ph_distance_batch(const phnsw_store *st, const float *q_dev, uint32_t query_id, const uint32_t *ids_dev, uint32_t k,
                       float *out_dev, hipStream_t s) {
   if (k == 0) return 0;
-  uint32_t nv4 = st->ld / 4;
-  uint32_t blocks = std::min<uint32_t>((k + 3) / 4, 2048);
-#define PH_LAUNCH(NV)                                                                                      \
-  hipLaunchKernelGGL(ph_distance_batch_kernel<NV>, dim3(blocks), dim3(256), 0, s, st->rows, st->ld, nv4,  \
-                     st->metric, q_dev, ids_dev, k, st->n, out_dev)
-  if (nv4 <= 64)
-    PH_LAUNCH(1);
-  else if (nv4 <= 192)
-    PH_LAUNCH(3);
-  else if (nv4 <= 384)
-    PH_LAUNCH(6);
-  else {
-    ph_set_error("dim %u unsupported (max 1536)", st->dim);
-    return PHNSW_E_UNSUPPORTED;
-  }
+  PhDistArgs da = ph_dist_args(st);
+  if (st->codes) {
+    size_t lds = ph_pq_lds_bytes(st);
+    if (lds > 48 * 1024)
+      PH_HIP(hipFuncSetAttribute((const void *)ph_distance_batch_kernel<DistPQ>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t blocks = std::min<uint32_t>((k + 63) / 64, 256);
+    hipLaunchKernelGGL(ph_distance_batch_kernel<DistPQ>, dim3(blocks), dim3(64), lds, s, da, q_dev, query_id, ids_dev,
+                       k, st->n, out_dev);
+  } else {
+    uint32_t nv4 = st->ld / 4;
+    uint32_t blocks = std::min<uint32_t>((k + 63) / 64, 4096);
+#define PH_LAUNCH(NV)                                                                                             \
+  hipLaunchKernelGGL(ph_distance_batch_kernel<DistF32<NV>>, dim3(blocks), dim3(64), 0, s, da, q_dev, query_id,   \
+                     ids_dev, k, st->n, out_dev)
+    if (nv4 <= 64)
+      PH_LAUNCH(1);
+    else if (nv4 <= 192)
+      PH_LAUNCH(3);
+    else if (nv4 <= 384)
+      PH_LAUNCH(6);
+    else {
+      ph_set_error("dim %u unsupported (max 1536)", st->dim);
+      return PHNSW_E_UNSUPPORTED;
+    }
 #undef PH_LAUNCH
+  }
   PH_HIP(hipGetLastError());
   return 0;
 }

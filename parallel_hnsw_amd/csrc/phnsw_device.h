@@ -170,3 +170,77 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
   }
   return myd;
 }
+
+// ------------------------------------------------------------------ distance policies
+// The traversal kernels are written once and instantiated per policy:
+//   DistF32<NV>: the query in registers, candidates = f32 rows (wave per row, 4 in flight)
+//   DistPQ:      product-quantised store: a per-query table T[m][ksub] in LDS
+//                (T[j][k] = <q_sub_j, c_jk> or |q_sub_j - c_jk|^2), candidates = u8 code
+//                rows, one LANE per candidate, distance = sum_j T[j][code_j] added in j order.
+template <int NV>
+struct DistF32 {
+  float4 qv[NV];
+  __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *, uint32_t lane) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      qv[k] = (c < d.nv4) ? ((const float4 *)q)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void prepare_stored(const PhDistArgs &d, uint32_t vid, float *lds, uint32_t lane) {
+    prepare_raw(d, d.vecs + (uint64_t)vid * d.ld, lds, lane);
+  }
+  __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
+    return batch_distances<NV>(d.vecs, d.ld, d.nv4, d.metric, d.metric == PHNSW_METRIC_L2, qv, mask, vid, lane);
+  }
+};
+
+struct DistPQ {
+  float *T;  // LDS [m][ksub]
+  // q_sub_j comes from `q` (raw query, dim floats) or from the codebook entry of a stored code
+  __device__ __forceinline__ void build(const PhDistArgs &d, const float *q, const uint8_t *qcodes, float *lds,
+                                        uint32_t lane) {
+    T = lds;
+    const bool l2 = d.metric == PHNSW_METRIC_L2;
+    for (uint32_t j = 0; j < d.m; j++) {
+      const float *qs = q ? q + (uint64_t)j * d.dsub
+                          : d.codebook + ((uint64_t)j * d.ksub + qcodes[j]) * d.dsub;
+      for (uint32_t k = lane; k < d.ksub; k += 64) {
+        const float *c = d.codebook + ((uint64_t)j * d.ksub + k) * d.dsub;
+        float acc = 0.f;
+        for (uint32_t e = 0; e < d.dsub; e++) {
+          if (l2) {
+            float df = qs[e] - c[e];
+            acc = fmaf(df, df, acc);
+          } else {
+            acc = fmaf(qs[e], c[e], acc);
+          }
+        }
+        T[j * d.ksub + k] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *lds, uint32_t lane) {
+    build(d, q, nullptr, lds, lane);
+  }
+  __device__ __forceinline__ void prepare_stored(const PhDistArgs &d, uint32_t vid, float *lds, uint32_t lane) {
+    build(d, nullptr, d.codes + (uint64_t)vid * d.m, lds, lane);
+  }
+  __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
+    float r = 0.f;
+    if ((mask >> lane) & 1ull) {
+      const uint32_t *row = (const uint32_t *)(d.codes + (uint64_t)vid * d.m);  // m % 4 == 0
+      for (uint32_t w = 0; w < d.m / 4; w++) {
+        uint32_t cw = row[w];
+        uint32_t j = 4 * w;
+        r = __fadd_rn(r, T[(j + 0) * d.ksub + (cw & 0xFF)]);
+        r = __fadd_rn(r, T[(j + 1) * d.ksub + ((cw >> 8) & 0xFF)]);
+        r = __fadd_rn(r, T[(j + 2) * d.ksub + ((cw >> 16) & 0xFF)]);
+        r = __fadd_rn(r, T[(j + 3) * d.ksub + (cw >> 24)]);
+      }
+      r = finalize_metric(r, d.metric);
+    }
+    return r;
+  }
+};

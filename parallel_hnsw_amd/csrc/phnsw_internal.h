@@ -42,9 +42,25 @@ struct PhLayerHost {
   bool identity = false;
 };
 
+// what a distance evaluation needs: the f32 store, or -- for a product-quantised store --
+// code rows + per-subspace codebooks (pq.hip)
+struct PhDistArgs {
+  const float *vecs;  // [n][ld] f32 rows (nullptr for a PQ store)
+  uint32_t ld, nv4;
+  int metric;
+  const uint8_t *codes;   // [n][m] u8 codes (PQ store)
+  const float *codebook;  // [m][ksub][dsub]
+  uint32_t m, ksub, dsub;
+};
+
 struct phnsw_store {
   int device = 0;
   float *rows = nullptr;  // [n][ld] flat, HBM
+  // product-quantised store (phnsw_store_create_pq): rows == nullptr, dim/ld describe the
+  // full vectors a query has
+  uint8_t *codes = nullptr;
+  float *codebook = nullptr;
+  uint32_t pq_m = 0, pq_ksub = 0, pq_dsub = 0;
   bool owns_rows = true;
   uint64_t n = 0;
   uint32_t dim = 0, ld = 0;
@@ -77,10 +93,7 @@ struct phnsw_index {
 
 // ---- kernel argument block for the batched greedy search ----
 struct PhSearchArgs {
-  const float *vecs;
-  uint32_t ld;   // floats per row
-  uint32_t nv4;  // ld / 4
-  int metric;
+  PhDistArgs dist;
   const float *queries;  // [nq][ldq] or nullptr
   uint32_t ldq;
   const uint32_t *qids;     // or nullptr
@@ -119,15 +132,30 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream);
 int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uint32_t ovf_cap);
 void ph_workspace_free(PhWorkspace &ws);
-uint32_t ph_search_slots(uint32_t ef, uint32_t nv4);
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds);
+static inline PhDistArgs ph_dist_args(const phnsw_store *s) {
+  PhDistArgs d;
+  d.vecs = s->rows;
+  d.ld = s->ld;
+  d.nv4 = s->ld / 4;
+  d.metric = s->metric;
+  d.codes = s->codes;
+  d.codebook = s->codebook;
+  d.m = s->pq_m;
+  d.ksub = s->pq_ksub;
+  d.dsub = s->pq_dsub;
+  return d;
+}
+static inline size_t ph_pq_lds_bytes(const phnsw_store *s) { return s->codes ? (size_t)s->pq_m * s->pq_ksub * 4 : 0; }
 
 // misc kernels (misc.hip)
 int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                   uint64_t seed, int normalize, hipStream_t s);
 int ph_synth_clustered_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld, uint64_t seed,
                             uint32_t n_clusters, float noise, hipStream_t s);
-int ph_distance_batch(const phnsw_store *st, const float *q_dev, const uint32_t *ids_dev, uint32_t k,
-                      float *out_dev, hipStream_t s);
+// q_dev == nullptr: the query is Stored(query_id)
+int ph_distance_batch(const phnsw_store *st, const float *q_dev, uint32_t query_id, const uint32_t *ids_dev,
+                      uint32_t k, float *out_dev, hipStream_t s);
 int ph_fill_u32(uint32_t *p, uint32_t v, uint64_t n, hipStream_t s);
 int ph_scatter_vec2node(const uint32_t *nodes, uint32_t n, uint32_t *vec2node, hipStream_t s);
 int ph_count_nan(const float *rows, uint64_t n_floats, uint32_t *out_count_dev, hipStream_t s);

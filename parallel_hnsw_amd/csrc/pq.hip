@@ -1,0 +1,313 @@
+// Product quantisation on gfx950 (BASELINE config 5; reference src/pq.rs).
+//
+// What the reference has (pq.rs:61-81, 261-364): a codebook of centroid sub-vectors picked at
+// random from the data (random_centroids, :261-285), quantize = nearest centroid per
+// sub-vector (through an HNSW over the centroids, :61-71), an Hnsw over the code rows whose
+// comparator reconstructs both sides and applies the full metric (test comparators
+// :585-599; PartialDistance is todo!()), and a search that re-ranks the quantised result
+// with the full-precision comparator and sorts by (d, id) (:346-364).
+//
+// What is built here: m sub-spaces of dsub = dim/m floats, one
+// codebook of ksub <= 256 centroids PER sub-space, u8 codes (m bytes per vector).  A PQ
+// store is a `phnsw_store` whose rows are code rows; every traversal kernel runs on it
+// through the DistPQ policy (phnsw_device.h): a per-query table T[m][ksub] in LDS (96 KiB at
+// m=96, ksub=256) -- ADC for raw queries, and for Stored queries the table of the
+// reconstruction, which makes code-vs-code distances symmetric sums of centroid-pair terms
+// (the reference's PartialDistance idea).  Encoding is the exact nearest centroid (the
+// reference's HNSW-over-centroids approximates it).
+//
+//   ph_pq_gather_codebook_kernel   random_centroids, per sub-space
+//   ph_pq_encode_kernel            Quantizer::quantize for every vector, one wave per vector
+//   ph_pq_reconstruct_kernel       Quantizer::reconstruct
+//   ph_pq_rerank_kernel            the re-rank + sort tail of QuantizedHnsw::search
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "phnsw_device.h"
+
+__global__ void ph_pq_gather_codebook_kernel(const float *rows, uint32_t ld, const uint32_t *sample, uint32_t m,
+                                             uint32_t ksub, uint32_t dsub, float *codebook) {
+  uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;  // (j, k, e)
+  uint32_t total = m * ksub * dsub;
+  if (x >= total) return;
+  uint32_t e = x % dsub, k = (x / dsub) % ksub, j = x / (dsub * ksub);
+  codebook[x] = rows[(uint64_t)sample[k] * ld + j * dsub + e];
+}
+
+// one wave per vector; per sub-space every lane scores ksub/64 centroids with a sequential
+// fma chain over the dsub components, then the wave takes the minimum of (distance, k)
+__global__ __launch_bounds__(64) void ph_pq_encode_kernel(const float *rows, uint32_t ld, uint64_t n, uint32_t m,
+                                                          uint32_t ksub, uint32_t dsub, const float *codebook,
+                                                          uint8_t *codes) {
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const float *x = rows + i * ld;
+    for (uint32_t j = 0; j < m; j++) {
+      const float *xs = x + j * dsub;
+      uint64_t best = KEY_NONE;
+      for (uint32_t k = lane; k < ksub; k += 64) {
+        const float *c = codebook + ((uint64_t)j * ksub + k) * dsub;
+        float acc = 0.f;
+        for (uint32_t e = 0; e < dsub; e++) {
+          float df = xs[e] - c[e];
+          acc = fmaf(df, df, acc);
+        }
+        uint64_t key = ((uint64_t)__float_as_uint(acc) << 32) | k;  // acc >= 0: bits order as floats
+        best = key < best ? key : best;
+      }
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) {
+        uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(best >> 32), s) << 32) | __shfl_xor((uint32_t)best, s);
+        best = o < best ? o : best;
+      }
+      if (lane == 0) codes[i * m + j] = (uint8_t)(best & 0xFF);
+    }
+  }
+}
+
+__global__ void ph_pq_reconstruct_kernel(const uint8_t *codes, uint64_t n, uint32_t m, uint32_t ksub, uint32_t dsub,
+                                         const float *codebook, float *out, uint32_t ld) {
+  uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t dim = (uint64_t)m * dsub;
+  if (x >= n * dim) return;
+  uint64_t i = x / dim;
+  uint32_t c = (uint32_t)(x % dim), j = c / dsub, e = c % dsub;
+  out[i * ld + c] = codebook[((uint64_t)j * ksub + codes[i * m + j]) * dsub + e];
+}
+
+// re-rank: full-precision distance of the query to each of its quantised results, then
+// sort by (d, id)  pq.rs:354-361.  One wave per query, ids in/out [nq][ef].
+template <int NV>
+__global__ __launch_bounds__(64) void ph_pq_rerank_kernel(PhDistArgs full, const float *queries, uint32_t ldq,
+                                                          uint32_t nq, uint32_t ef, const uint32_t *len,
+                                                          uint32_t *ids, float *d) {
+  extern __shared__ uint64_t rk[];  // [ef] keys, [ef] sorted
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    DistF32<NV> dist;
+    dist.prepare_raw(full, queries + (uint64_t)q * ldq, nullptr, lane);
+    const uint32_t cnt = min(len[q], ef);
+    for (uint32_t base = 0; base < cnt; base += 64) {
+      uint32_t i = base + lane;
+      uint32_t id = i < cnt ? ids[(uint64_t)q * ef + i] : 0u;
+      float dd = dist.batch(full, __ballot(i < cnt), id, lane);
+      if (i < cnt) rk[i] = mkkey(dd, id);
+    }
+    __syncthreads();
+    for (uint32_t c = lane; c < cnt; c += 64) {
+      uint64_t kc = rk[c];
+      uint32_t rank = 0;
+      for (uint32_t e = 0; e < cnt; e++) {
+        uint64_t ke = rk[e];
+        rank += (ke < kc || (ke == kc && e < c)) ? 1u : 0u;
+      }
+      rk[ef + rank] = kc;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < ef; i += 64) {
+      bool live = i < cnt;
+      uint64_t k = live ? rk[ef + i] : 0;
+      uint32_t fk = (uint32_t)(k >> 32);
+      uint32_t u = (fk & 0x80000000u) ? (fk ^ 0x80000000u) : ~fk;
+      ids[(uint64_t)q * ef + i] = live ? ((uint32_t)k & IDM) : PH_EMPTY32;
+      d[(uint64_t)q * ef + i] = live ? __uint_as_float(u) : PH_FMAX;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+
+#define PH_TRYQ(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+
+extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) {
+  if (!full || !out || full->codes || !full->rows || m == 0 || ksub == 0 || ksub > 256 || (m % 4) ||
+      (full->dim % m) || ksub > full->n) {
+    ph_set_error("phnsw_store_create_pq: need an f32 store, m %% 4 == 0, dim %% m == 0, 1 <= ksub <= min(256, n)");
+    return PHNSW_E_INVALID;
+  }
+  if ((size_t)m * ksub * 4 > 150 * 1024) {
+    ph_set_error("phnsw_store_create_pq: table m*ksub*4 = %zu bytes does not fit the 160 KiB LDS of a CU",
+                 (size_t)m * ksub * 4);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  PH_HIP(hipSetDevice(full->device));
+  const uint32_t dsub = full->dim / m;
+  phnsw_store *s = new phnsw_store();
+  s->device = full->device;
+  s->n = full->n;
+  s->dim = full->dim;
+  s->ld = full->ld;
+  s->metric = full->metric;
+  s->rows = nullptr;
+  s->pq_m = m;
+  s->pq_ksub = ksub;
+  s->pq_dsub = dsub;
+  uint32_t *sample_d = nullptr;
+  int rc = 0;
+  hipError_t e = hipMalloc(&s->codes, (size_t)s->n * m);
+  if (e == hipSuccess) e = hipMalloc(&s->codebook, (size_t)m * ksub * dsub * 4);
+  if (e == hipSuccess) e = hipMalloc(&sample_d, (size_t)ksub * 4);
+  if (e != hipSuccess) rc = ph_hip_fail(e, "pq alloc", __FILE__, __LINE__);
+  if (!rc) {
+    // random_centroids (pq.rs:261-285): the sub-vectors of ksub randomly selected vectors
+    std::vector<uint64_t> perm(s->n);
+    for (uint64_t i = 0; i < s->n; i++) perm[i] = i;
+    ph_shuffle_u64(perm.data(), s->n, seed ^ 0x9C0DEB00C5ULL);
+    std::vector<uint32_t> sample(ksub);
+    for (uint32_t k = 0; k < ksub; k++) sample[k] = (uint32_t)perm[k];
+    e = hipMemcpy(sample_d, sample.data(), (size_t)ksub * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq sample upload", __FILE__, __LINE__);
+  }
+  if (!rc) {
+    uint32_t total = m * ksub * dsub;
+    hipLaunchKernelGGL(ph_pq_gather_codebook_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, full->rows, full->ld,
+                       sample_d, m, ksub, dsub, s->codebook);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(s->n, 256u * 32u);
+    hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, full->rows, full->ld, s->n, m, ksub, dsub,
+                       s->codebook, s->codes);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq encode", __FILE__, __LINE__);
+  }
+  if (sample_d) hipFree(sample_d);
+  if (rc) {
+    if (s->codes) hipFree(s->codes);
+    if (s->codebook) hipFree(s->codebook);
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) {
+  if (!s || !s->codes) {
+    ph_set_error("not a product-quantised store");
+    return PHNSW_E_INVALID;
+  }
+  if (m) *m = s->pq_m;
+  if (ksub) *ksub = s->pq_ksub;
+  if (dsub) *dsub = s->pq_dsub;
+  return 0;
+}
+
+extern "C" int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook) {
+  if (!s || !s->codes) {
+    ph_set_error("not a product-quantised store");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  if (codes) PH_HIP(hipMemcpy(codes, s->codes, (size_t)s->n * s->pq_m, hipMemcpyDeviceToHost));
+  if (codebook)
+    PH_HIP(hipMemcpy(codebook, s->codebook, (size_t)s->pq_m * s->pq_ksub * s->pq_dsub * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// QuantizedHnsw::search  pq.rs:346-364 for a batch: (optionally quantise the query like the
+// reference :351-352, default = asymmetric: the raw query meets the codes), search the graph
+// over the code rows, re-rank with the full-precision store, sort by (d, id).
+extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *full, const float *queries, uint64_t nq,
+                                     const phnsw_search_params *sp, int quantize_query, uint64_t *out_ids,
+                                     float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+  if (!ix || !full || !queries || !sp || !out_ids || !out_d || !out_len || !ix->store->codes || !full->rows ||
+      full->n != ix->store->n || full->dim != ix->store->dim || nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 ||
+      sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
+    ph_set_error("phnsw_pq_search_batch: need an index over a PQ store, its full-precision store and valid parameters");
+    return PHNSW_E_INVALID;
+  }
+  if (nq == 0) return 0;
+  const phnsw_store *ps = ix->store;
+  PH_HIP(hipSetDevice(ps->device));
+  const uint32_t ef = (uint32_t)sp->number_of_candidates;
+  float *qd = nullptr, *qq = nullptr, *od = nullptr;
+  uint32_t *oid = nullptr, *olen = nullptr, *ost = nullptr, *ostat = nullptr;
+  uint8_t *qcodes = nullptr;
+  int rc = 0;
+  hipError_t e = hipMalloc(&qd, (size_t)nq * full->ld * 4);
+  if (e == hipSuccess && full->ld != full->dim) e = hipMemset(qd, 0, (size_t)nq * full->ld * 4);
+  if (e == hipSuccess)
+    e = hipMemcpy2D(qd, (size_t)full->ld * 4, queries, (size_t)full->dim * 4, (size_t)full->dim * 4, nq,
+                    hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&oid, (size_t)nq * ef * 4);
+  if (e == hipSuccess) e = hipMalloc(&od, (size_t)nq * ef * 4);
+  if (e == hipSuccess) e = hipMalloc(&olen, nq * 4);
+  if (e == hipSuccess) e = hipMalloc(&ost, nq * 8);
+  if (e == hipSuccess) e = hipMalloc(&ostat, nq * 4);
+  const float *qsearch = qd;
+  if (e == hipSuccess && quantize_query) {
+    e = hipMalloc(&qcodes, (size_t)nq * ps->pq_m);
+    if (e == hipSuccess) e = hipMalloc(&qq, (size_t)nq * full->ld * 4);
+    if (e == hipSuccess) e = hipMemset(qq, 0, (size_t)nq * full->ld * 4);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ph_pq_encode_kernel, dim3((uint32_t)std::min<uint64_t>(nq, 8192)), dim3(64), 0, 0, qd,
+                         full->ld, nq, ps->pq_m, ps->pq_ksub, ps->pq_dsub, ps->codebook, qcodes);
+      uint64_t tot = nq * full->dim;
+      hipLaunchKernelGGL(ph_pq_reconstruct_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, 0, qcodes, nq,
+                         ps->pq_m, ps->pq_ksub, ps->pq_dsub, ps->codebook, qq, full->ld);
+      e = hipGetLastError();
+      qsearch = qq;
+    }
+  }
+  if (e != hipSuccess) rc = ph_hip_fail(e, "pq search staging", __FILE__, __LINE__);
+  if (!rc)
+    rc = ph_search_device(ix, qsearch, full->ld, nullptr, nq, sp, 0, nullptr, oid, od, olen, ost, ostat, 0, 0, 0);
+  std::vector<uint32_t> h_status(nq);
+  if (!rc) {
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_status.data(), ostat, nq * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq search", __FILE__, __LINE__);
+    for (uint64_t i = 0; !rc && i < nq; i++)
+      if (h_status[i]) {
+        ph_set_error("pq search: query %llu failed with status %u", (unsigned long long)i, h_status[i]);
+        rc = h_status[i] == 4 ? PHNSW_E_MISSING_NODE : PHNSW_E_OVERFLOW;
+      }
+  }
+  if (!rc) {
+    // full_comparator().compare_vec(Stored(id), v) for every result, sort_by_key (d, id)
+    PhDistArgs fa = ph_dist_args(full);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, 256u * 16u);
+    size_t lds = (size_t)ef * 16;
+    uint32_t nv4 = full->ld / 4;
+    if (nv4 <= 64)
+      hipLaunchKernelGGL(ph_pq_rerank_kernel<1>, dim3(grid), dim3(64), lds, 0, fa, qd, full->ld, (uint32_t)nq, ef, olen, oid, od);
+    else if (nv4 <= 192)
+      hipLaunchKernelGGL(ph_pq_rerank_kernel<3>, dim3(grid), dim3(64), lds, 0, fa, qd, full->ld, (uint32_t)nq, ef, olen, oid, od);
+    else if (nv4 <= 384)
+      hipLaunchKernelGGL(ph_pq_rerank_kernel<6>, dim3(grid), dim3(64), lds, 0, fa, qd, full->ld, (uint32_t)nq, ef, olen, oid, od);
+    else {
+      ph_set_error("dim %u unsupported (max 1536)", full->dim);
+      rc = PHNSW_E_UNSUPPORTED;
+    }
+    if (!rc) {
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) rc = ph_hip_fail(e, "pq rerank", __FILE__, __LINE__);
+    }
+  }
+  if (!rc) {
+    std::vector<uint32_t> h_ids((size_t)nq * ef), h_len(nq), h_st(2 * nq);
+    e = hipMemcpy(h_ids.data(), oid, h_ids.size() * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_d, od, (size_t)nq * ef * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_len.data(), olen, nq * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_st.data(), ost, nq * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+      rc = ph_hip_fail(e, "pq readback", __FILE__, __LINE__);
+    else {
+      for (size_t i = 0; i < h_ids.size(); i++) out_ids[i] = h_ids[i] == PH_EMPTY32 ? PHNSW_EMPTY : h_ids[i];
+      for (uint64_t i = 0; i < nq; i++) out_len[i] = h_len[i];
+      if (out_stats)
+        for (uint64_t i = 0; i < 2 * nq; i++) out_stats[i] = h_st[i];
+    }
+  }
+  for (void *p : {(void *)qd, (void *)qq, (void *)od, (void *)oid, (void *)olen, (void *)ost, (void *)ostat, (void *)qcodes})
+    if (p) hipFree(p);
+  return rc;
+}

@@ -37,7 +37,7 @@
 
 #include "phnsw_device.h"
 
-template <int CAPC, int NV>
+template <int CAPC, class Dist>
 __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   extern __shared__ uint32_t smem[];
   constexpr int CAP = CAPC * 64;
@@ -46,14 +46,13 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   uint32_t *Qid = smem + 2 * CAP;          // layer queue: NodeIds | EXPF (lib.rs:264)
   float *Qd = (float *)(smem + 3 * CAP);   //
   uint32_t *S = smem + 4 * CAP;            // prefix scratch [CAP + 64]
+  float *dist_lds = (float *)(smem + 5 * CAP + 64);  // DistPQ: the query's lookup table
 
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
   uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
   uint2 *ovf = a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
   const uint32_t ef = a.ef;
-  const uint32_t nv4 = a.nv4;
-  const bool l2 = a.metric == PHNSW_METRIC_L2;
 
   for (;;) {
     uint32_t q = 0;
@@ -63,15 +62,11 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
 
     const uint32_t last_layer = a.n_layers - 1;
     uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[q] : (a.qids ? a.qids[q] : 0u);
-    const float4 *qrow = (a.queries && !a.knn_mode)
-                             ? (const float4 *)(a.queries + (uint64_t)q * a.ldq)
-                             : (const float4 *)(a.vecs + (uint64_t)qvec * a.ld);
-    float4 qv[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      uint32_t c = lane + 64u * k;
-      qv[k] = (c < nv4) ? qrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    Dist dist;
+    if (a.queries && !a.knn_mode)
+      dist.prepare_raw(a.dist, a.queries + (uint64_t)q * a.ldq, dist_lds, lane);
+    else
+      dist.prepare_stored(a.dist, qvec, dist_lds, lane);
     const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
     uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
     uint32_t clen = 0;
@@ -79,8 +74,8 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     if (!a.knn_mode) {
       // entry_vector + distance_from_entry  search.rs:101-111
       uint32_t entry = a.layers[0].nodes[0];
-      float r = wave_sum(row_partial<NV>((const float4 *)(a.vecs + (uint64_t)entry * a.ld), qv, nv4, lane, l2));
-      float d0 = finalize_metric(r, a.metric);
+      float d0 = dist.batch(a.dist, 1ull, entry, lane);
+      d0 = __uint_as_float(rl32(__float_as_uint(d0), 0));
       n_dist = 1;
       if (lane == 0) {
         Cid[0] = entry;
@@ -204,7 +199,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         if (fresh) vid = identity ? nb : L.nodes[nb];
 
         // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202
-        const float myd = batch_distances<NV>(a.vecs, a.ld, nv4, a.metric, l2, qv, fm, vid, lane);
+        const float myd = dist.batch(a.dist, fm, vid, lane);
 
         // candidates.merge_pairs(sorted batch)  lib.rs:206,226 / priority_queue.rs:109-144,
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
@@ -447,30 +442,40 @@ typedef void (*ph_search_fn)(PhSearchArgs);
 static int pick_capc(uint32_t ef) { return ef <= 128 ? 2 : (ef <= 512 ? 8 : (ef <= 1024 ? 16 : 0)); }
 static int pick_nv(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
 
+// nv == 0 selects the product-quantised policy
 static ph_search_fn pick_kernel(int capc, int nv) {
 #define PH_K(C, N) \
-  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, N>;
+  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, DistF32<N>>;
+#define PH_KQ(C) \
+  if (capc == C && nv == 0) return (ph_search_fn)ph_search_kernel<C, DistPQ>;
   PH_K(2, 1) PH_K(2, 3) PH_K(2, 6)
   PH_K(8, 1) PH_K(8, 3) PH_K(8, 6)
   PH_K(16, 1) PH_K(16, 3) PH_K(16, 6)
+  PH_KQ(2) PH_KQ(8) PH_KQ(16)
 #undef PH_K
+#undef PH_KQ
   return nullptr;
 }
 
-static size_t lds_bytes(int capc) { return (size_t)(5 * capc * 64 + 64) * 4; }
+static size_t lds_bytes(int capc, size_t pq_lds) { return (size_t)(5 * capc * 64 + 64) * 4 + pq_lds; }
 
-uint32_t ph_search_slots(uint32_t ef, uint32_t nv4) {
-  int capc = pick_capc(ef), nv = pick_nv(nv4);
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds) {
+  int capc = pick_capc(ef), nv = pq ? 0 : pick_nv(nv4);
+  if (!capc || (!pq && !nv)) return 0;
   ph_search_fn fn = pick_kernel(capc, nv);
   if (!fn) return 0;
   int dev = 0;
   hipGetDevice(&dev);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  size_t lds = lds_bytes(capc, pq_lds);
+  if (lds > 64 * 1024) {
+    if (lds > 160 * 1024) return 0;
+    if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+  }
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds_bytes(capc)) != hipSuccess ||
-      per_cu <= 0)
-    per_cu = 8;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds) != hipSuccess || per_cu <= 0)
+    per_cu = 1;
   int cap = 16;
   if (const char *e = getenv("PHNSW_WAVES_PER_CU")) cap = atoi(e) > 0 ? atoi(e) : cap;
   per_cu = std::min(per_cu, cap);
@@ -490,9 +495,10 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   uint64_t max_nodes = 0;
   for (auto &l : ix->layers) max_nodes = std::max<uint64_t>(max_nodes, l.n_nodes);
   uint64_t words = (max_nodes + 31) / 32 + 1;
-  uint32_t slots = ph_search_slots(ef, ix->store->ld / 4);
+  uint32_t slots = ph_search_slots(ef, ix->store->ld / 4, ix->store->codes != nullptr, ph_pq_lds_bytes(ix->store));
   if (slots == 0) {
-    ph_set_error("unsupported search shape: ef=%u dim=%u (ef <= 1024, dim <= 1536)", ef, ix->store->dim);
+    ph_set_error("unsupported search shape: ef=%u dim=%u (ef <= 1024, dim <= 1536; PQ table + queue <= 160 KB LDS)", ef,
+                 ix->store->dim);
     return PHNSW_E_UNSUPPORTED;
   }
   if (!ws.counter) {
@@ -524,10 +530,12 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
 }
 
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream) {
-  int capc = pick_capc(a.ef), nv = pick_nv(a.nv4);
-  ph_search_fn fn = pick_kernel(capc, nv);
+  const bool pq = ix->store->codes != nullptr;
+  const size_t pq_lds = ph_pq_lds_bytes(ix->store);
+  int capc = pick_capc(a.ef), nv = pq ? 0 : pick_nv(a.dist.nv4);
+  ph_search_fn fn = (capc && (pq || nv)) ? pick_kernel(capc, nv) : nullptr;
   if (!fn) {
-    ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.nv4);
+    ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);
     return PHNSW_E_UNSUPPORTED;
   }
   a.visited = ws.visited;
@@ -535,12 +543,12 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   a.ovf = ws.ovf;
   a.ovf_cap = ws.ovf_cap;
   a.counter = ws.counter;
-  uint32_t slots = std::min<uint32_t>(ph_search_slots(a.ef, a.nv4), ws.n_slots);
+  uint32_t slots = std::min<uint32_t>(ph_search_slots(a.ef, a.dist.nv4, pq, pq_lds), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
   PH_HIP(hipMemsetAsync(ws.counter, 0, 4, stream));
   PH_HIP(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc), stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc, pq_lds), stream, a);
   PH_HIP(hipGetLastError());
   PH_HIP(hipEventRecord(ws.ev1, stream));
   ws.timed = true;

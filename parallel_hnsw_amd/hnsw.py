@@ -121,6 +121,63 @@ class VectorStore:
                 pass
 
 
+class PqStore(VectorStore):
+    """product-quantised view of a VectorStore (pq.rs): u8 codes over per-sub-space codebooks"""
+
+    def __init__(self, full, m, ksub=256, seed=0):
+        h = C.c_void_p()
+        check(lib().phnsw_store_create_pq(full._h, m, ksub, seed, C.byref(h)))
+        VectorStore.__init__(self, _handle=h, device=full.device)
+        self.full = full
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().phnsw_pq_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.m, self.ksub, self.dsub = a.value, b.value, c.value
+
+    def codes(self):
+        out = np.empty((self.n, self.m), dtype=np.uint8)
+        check(lib().phnsw_pq_read(self._h, _p(out), None))
+        return out
+
+    def codebook(self):
+        out = np.empty((self.m, self.ksub, self.dsub), dtype=np.float32)
+        check(lib().phnsw_pq_read(self._h, None, _p(out)))
+        return out
+
+
+class QuantizedHnsw:
+    """QuantizedHnsw (pq.rs:120-131, 287-364): quantizer + Hnsw over the codes + full comparator"""
+
+    def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None):
+        """QuantizedHnsw::new(number_of_centroids, comparator, bp): per-sub-space codebooks of
+        `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes"""
+        m = m or max(4, comparator.dim // 8)
+        self.full = comparator
+        self.store = PqStore(comparator, m, number_of_centroids, seed)
+        vids = np.arange(comparator.n, dtype=np.uint64) if vids is None else vids
+        self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters())
+
+    def search_batch(self, queries, sp=None, quantize_query=False, stats=False):
+        sp = sp or SearchParameters()
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        assert q.shape[1] == self.full.dim
+        nq, ef = q.shape[0], sp.number_of_candidates
+        ids = np.empty((nq, ef), dtype=np.uint64)
+        d = np.empty((nq, ef), dtype=np.float32)
+        ln = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros((nq, 2), dtype=np.uint64) if stats else None
+        check(lib().phnsw_pq_search_batch(self.hnsw._h, self.full._h, _p(q), nq, C.byref(sp), int(quantize_query),
+                                          _p(ids), _p(d), _p(ln), _p(st)))
+        return (ids, d, ln, st) if stats else (ids, d, ln)
+
+    def search(self, v, sp=None):
+        """QuantizedHnsw::search(v, sp)  pq.rs:346-364"""
+        ids, d, ln = self.search_batch(v.vec if isinstance(v, Unstored) else v, sp)
+        return [(int(ids[0, i]), d[0, i]) for i in range(int(ln[0]))]
+
+    def vector_count(self):
+        return self.hnsw.vector_count()
+
+
 class Layer:
     """Layer { neighborhood_size, nodes, neighbors }  lib.rs:85-91 (host copies, u64)"""
 
