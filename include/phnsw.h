@@ -238,6 +238,12 @@ int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *full, const 
                           const phnsw_search_params *sp, int quantize_query, uint64_t *out_ids,
                           float *out_d, uint64_t *out_len, uint64_t *out_stats);
 
+/* zero-copy form (asymmetric queries): search + re-rank kernels enqueued on `stream`, u32 ids */
+int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_store *full, const float *queries_dev,
+                                 uint32_t ldq, uint64_t nq, const phnsw_search_params *sp,
+                                 uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
+                                 uint32_t *out_stats_dev, uint32_t *status_dev, void *stream);
+
 /* Hnsw::knn  src/lib.rs:905-928 : bottom layer, out [node_count][k] */
 int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
               float *out_d, uint64_t *out_len);

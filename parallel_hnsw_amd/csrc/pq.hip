@@ -311,3 +311,40 @@ extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *f
     if (p) hipFree(p);
   return rc;
 }
+
+// zero-copy form of phnsw_pq_search_batch (asymmetric queries): search kernel + re-rank
+// kernel enqueued on `stream`, u32 ids, no synchronisation.
+extern "C" int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_store *full, const float *queries_dev,
+                                            uint32_t ldq, uint64_t nq, const phnsw_search_params *sp,
+                                            uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
+                                            uint32_t *out_stats_dev, uint32_t *status_dev, void *stream) {
+  if (!ix || !full || !queries_dev || !sp || !out_ids_dev || !out_d_dev || !out_len_dev || !status_dev ||
+      !ix->store->codes || !full->rows || full->n != ix->store->n || full->dim != ix->store->dim ||
+      nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0 ||
+      ldq < full->ld || (ldq % 4)) {
+    ph_set_error("phnsw_pq_search_batch_device: invalid argument");
+    return PHNSW_E_INVALID;
+  }
+  if (nq == 0) return 0;
+  PH_HIP(hipSetDevice(full->device));
+  const uint32_t ef = (uint32_t)sp->number_of_candidates;
+  PH_TRYQ(ph_search_device(ix, queries_dev, ldq, nullptr, nq, sp, 0, nullptr, out_ids_dev, out_d_dev, out_len_dev,
+                           out_stats_dev, status_dev, 0, 0, (hipStream_t)stream));
+  PhDistArgs fa = ph_dist_args(full);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(nq, 256u * 16u);
+  size_t lds = (size_t)ef * 16;
+  uint32_t nv4 = full->ld / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (nv4 <= 64)
+    hipLaunchKernelGGL(ph_pq_rerank_kernel<1>, dim3(grid), dim3(64), lds, st, fa, queries_dev, ldq, (uint32_t)nq, ef, out_len_dev, out_ids_dev, out_d_dev);
+  else if (nv4 <= 192)
+    hipLaunchKernelGGL(ph_pq_rerank_kernel<3>, dim3(grid), dim3(64), lds, st, fa, queries_dev, ldq, (uint32_t)nq, ef, out_len_dev, out_ids_dev, out_d_dev);
+  else if (nv4 <= 384)
+    hipLaunchKernelGGL(ph_pq_rerank_kernel<6>, dim3(grid), dim3(64), lds, st, fa, queries_dev, ldq, (uint32_t)nq, ef, out_len_dev, out_ids_dev, out_d_dev);
+  else {
+    ph_set_error("dim %u unsupported (max 1536)", full->dim);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  PH_HIP(hipGetLastError());
+  return 0;
+}

@@ -169,6 +169,12 @@ class QuantizedHnsw:
                                           _p(ids), _p(d), _p(ln), _p(st)))
         return (ids, d, ln, st) if stats else (ids, d, ln)
 
+    def search_batch_device(self, nq, sp, queries, ldq, out_ids, out_d, out_len, status, out_stats=0, stream=0):
+        check(lib().phnsw_pq_search_batch_device(self.hnsw._h, self.full._h, C.c_void_p(queries), ldq, nq, C.byref(sp),
+                                                 C.c_void_p(out_ids), C.c_void_p(out_d), C.c_void_p(out_len),
+                                                 C.c_void_p(out_stats or None), C.c_void_p(status),
+                                                 C.c_void_p(stream or None)))
+
     def search(self, v, sp=None):
         """QuantizedHnsw::search(v, sp)  pq.rs:346-364"""
         ids, d, ln = self.search_batch(v.vec if isinstance(v, Unstored) else v, sp)
