@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--skip-iid", dest="no_iid", action="store_true", help="skip the secondary iid-uniform measurement")
+    ap.add_argument("--skip-pq", dest="no_pq", action="store_true", help="skip the BASELINE config-5 (PQ) measurement")
     args = ap.parse_args()
 
     import torch
@@ -279,6 +280,53 @@ def main():
         log("cpu baseline %.0f q/s on %d cores (%d queries in %.1f s)" % (sample / dt, cores, sample, dt))
         del oix, rows_h
 
+    pq = None
+    if rank == 0 and world == 1 and not args.no_pq and not args.ef:
+        # BASELINE configs[4]: PQ m=96, 8-bit codes, table in LDS, full-precision re-rank (pq.rs:346-364)
+        try:
+            t0 = time.time()
+            qh = ph.QuantizedHnsw(256, store, ph.BuildParameters(), m=96 if args.dim % 96 == 0 else 4)
+            torch.cuda.synchronize()
+            pq_build = time.time() - t0
+            log("pq: codebooks + codes + graph over codes in %.1f s" % pq_build)
+            ef_max = 1024
+            pids = torch.empty((args.nq, ef_max), dtype=torch.int32, device=dev)
+            pd_ = torch.empty((args.nq, ef_max), dtype=torch.float32, device=dev)
+            pln = torch.empty(args.nq, dtype=torch.int32, device=dev)
+            pst = torch.empty((args.nq, 2), dtype=torch.int32, device=dev)
+            pstatus = torch.empty(args.nq, dtype=torch.int32, device=dev)
+            best = None
+            for ef, pdp in [(128, 8), (300, 8), (512, 16), (1024, 32)]:
+                spq = ph.SearchParameters(ef, ef, pdp)
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    qh.search_batch_device(args.nq, spq, qstore.rows_dev, qstore.ld, pids.data_ptr(), pd_.data_ptr(),
+                                           pln.data_ptr(), pstatus.data_ptr(), pst.data_ptr(), stream=stream)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                rec = recall_at_10(pids.view(-1)[: args.nq * ef].view(args.nq, ef), gt)
+                log("pq sweep ef=%d pd=%d recall@10=%.4f %.0f q/s" % (ef, pdp, rec, args.nq / dt))
+                cur = {"ef": ef, "probe_depth": pdp, "recall_at_10": round(rec, 4), "queries_per_s": round(args.nq / dt),
+                       "distance_evals_per_query": float(pst[:, 0].float().mean()),
+                       "hops_per_query": float(pst[:, 1].float().mean())}
+                if best is None or (rec >= args.target_recall and not best["met"]):
+                    best = dict(cur, met=rec >= args.target_recall)
+                if rec >= args.target_recall:
+                    break
+            m_ = qh.store.m
+            bq = best["distance_evals_per_query"] * m_ + best["hops_per_query"] * 48 * 4 + best["ef"] * (store.ld * 4 + 12)
+            pq = {"workload": "configs[4]: %dx%d PQ m=%d, 8-bit codes (%d B/vector), table %d KiB in LDS, "
+                              "search over codes + f32 re-rank" % (args.n, args.dim, m_, m_, m_ * 256 * 4 // 1024),
+                  "build_s": round(pq_build, 1), "recall_target_met": best.pop("met"), **best,
+                  "algorithmic_bytes_per_query": round(bq),
+                  "roofline_gbs": round(best["queries_per_s"] * bq / 1e9, 1),
+                  "note": "latency bound: the 96 KiB table leaves one resident wave per CU"}
+            del qh, pids, pd_
+        except Exception as exc:
+            pq = {"error": repr(exc)}
+            log("pq measurement failed: %r" % (exc,))
+
     iid = None
     if rank == 0 and world == 1 and not args.no_iid and args.dataset != "iid" and not args.ef:
         # the reference's own data distribution (bigvec.rs:59-65) at the BASELINE setting ef=128
@@ -330,6 +378,7 @@ def main():
                          "algorithmic_bytes_per_launch": res["alg_bytes"]},
             "cpu_baseline": cpu,
             "secondary": iid,
+            "pq": pq,
             "sweep": res["sweep"],
         }
         print(json.dumps(line), flush=True)
