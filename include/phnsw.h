@@ -244,9 +244,25 @@ int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_store *full,
                                  uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
                                  uint32_t *out_stats_dev, uint32_t *status_dev, void *stream);
 
+/* ---- on-disk interchange with the Rust crate: serialize_hnsw / deserialize_hnsw
+ * (src/serialize.rs:33-209): <dir>/meta (JSON HNSWMeta), <dir>/comparator/ (this library's
+ * store; a crate user substitutes their own Serializable comparator), layer.meta.N (JSON),
+ * layer.nodes.N / layer.neighbors.N (raw native-endian u64, !0 = empty), N from the bottom.
+ * Deserialising needs the store the index was built over (the crate's C::Params role); a
+ * missing comparator entry is "Index not found" (serialize.rs:144-146). ---- */
+int phnsw_index_serialize(const phnsw_index *ix, const char *path);
+int phnsw_index_deserialize(phnsw_store *s, const char *path, phnsw_index **out);
+int phnsw_index_build_params(const phnsw_index *ix, phnsw_build_params *bp);
+
 /* Hnsw::knn  src/lib.rs:905-928 : bottom layer, out [node_count][k] */
 int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
               float *out_d, uint64_t *out_len);
+
+/* Hnsw::threshold_nn  src/lib.rs:930-962 : bottom layer; out [node_count][max_out], entries
+ * with distance < threshold, self removed; the device queue may double up to 1024 entries */
+int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,
+                       uint64_t initial_search_depth, uint64_t max_out, uint64_t *out_ids,
+                       float *out_d, uint64_t *out_len);
 
 #ifdef __cplusplus
 }

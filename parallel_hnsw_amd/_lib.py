@@ -88,6 +88,10 @@ SYMBOLS = {
     "phnsw_pq_search_batch": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(SearchParams), _i32, _vp, _vp, _vp, _vp]),
     "phnsw_pq_search_batch_device": (_i32, [_vp, _vp, _vp, _u32, _u64, C.POINTER(SearchParams), _vp, _vp, _vp, _vp,
                                             _vp, _vp]),
+    "phnsw_index_serialize": (_i32, [_vp, C.c_char_p]),
+    "phnsw_index_deserialize": (_i32, [_vp, C.c_char_p, _pp]),
+    "phnsw_index_build_params": (_i32, [_vp, C.POINTER(BuildParams)]),
+    "phnsw_threshold_nn": (_i32, [_vp, _f32, _u64, _u64, _u64, _vp, _vp, _vp]),
     "phnsw_knn": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
 }
 

@@ -504,7 +504,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
-                     uint32_t *out_hit) {
+                     uint32_t *out_hit, float threshold, uint32_t first_node) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -521,8 +521,11 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.knn_mode = knn_mode;
   a.out_stride = out_stride;
   a.out_hit = out_hit;
+  a.threshold = threshold;
+  a.first_node = first_node;
+  a.cap_max = knn_mode == 2 ? out_stride : 0;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
-  int rc = ph_workspace_ensure(ix, mix->ws, a.ef, ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
+  int rc = ph_workspace_ensure(ix, mix->ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;
   return ph_search_launch(ix, mix->ws, a, stream);
 }
@@ -735,4 +738,85 @@ extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth
     }
   }
   return 0;
+}
+
+// Hnsw::threshold_nn  src/lib.rs:930-962: per bottom-layer node a queue seeded with
+// (self, 0.0) that doubles (resize_capacity) until its last entry reaches the threshold;
+// result = entries below the threshold without self.  Nodes are processed in chunks; the
+// queue may grow to 1024 entries on the device.
+extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,
+                                  uint64_t initial_search_depth, uint64_t max_out, uint64_t *out_ids, float *out_d,
+                                  uint64_t *out_len) {
+  if (!ix || ix->layers.empty() || !out_ids || !out_d || !out_len || initial_search_depth == 0 ||
+      initial_search_depth > 1024 || probe_depth == 0 || max_out == 0) {
+    ph_set_error("phnsw_threshold_nn: initial_search_depth must be 1..1024, probe_depth >= 1");
+    return PHNSW_E_INVALID;
+  }
+  const phnsw_store *s = ix->store;
+  PH_HIP(hipSetDevice(s->device));
+  const PhLayerHost &L = ix->layers.back();
+  const uint32_t n = L.n_nodes, CAPMAX = 1024, CHUNK = 16384;
+  phnsw_search_params sp = {initial_search_depth, initial_search_depth, probe_depth};
+  std::vector<uint32_t> h_nodes(n);
+  PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
+  uint32_t *oid = nullptr, *olen = nullptr, *ostat = nullptr;
+  float *od = nullptr;
+  uint32_t cn = std::min(n, CHUNK);
+  hipError_t e = hipMalloc(&oid, (size_t)cn * CAPMAX * 4);
+  if (e == hipSuccess) e = hipMalloc(&od, (size_t)cn * CAPMAX * 4);
+  if (e == hipSuccess) e = hipMalloc(&olen, (size_t)cn * 4);
+  if (e == hipSuccess) e = hipMalloc(&ostat, (size_t)cn * 4);
+  int rc = e == hipSuccess ? 0 : ph_hip_fail(e, "threshold_nn staging", __FILE__, __LINE__);
+  std::vector<uint32_t> h_ids((size_t)cn * CAPMAX), h_len(cn), h_status(cn);
+  std::vector<float> h_d((size_t)cn * CAPMAX);
+  for (uint32_t first = 0; !rc && first < n; first += CHUNK) {
+    uint32_t cnt = std::min(CHUNK, n - first);
+    rc = ph_search_device(ix, nullptr, 0, nullptr, cnt, &sp, 0, nullptr, oid, od, olen, nullptr, ostat, 0, 2, 0, CAPMAX,
+                          nullptr, threshold, first);
+    if (rc) break;
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_ids.data(), oid, (size_t)cnt * CAPMAX * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_d.data(), od, (size_t)cnt * CAPMAX * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_len.data(), olen, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_status.data(), ostat, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      rc = ph_hip_fail(e, "threshold_nn readback", __FILE__, __LINE__);
+      break;
+    }
+    for (uint32_t x = 0; x < cnt && !rc; x++) {
+      uint64_t i = first + x;
+      if (h_status[x]) {
+        ph_set_error("threshold_nn: node %llu %s", (unsigned long long)i,
+                     h_status[x] == 6 ? "needs a queue beyond 1024 entries" : "overflowed the frontier workspace");
+        rc = h_status[x] == 6 ? PHNSW_E_UNSUPPORTED : PHNSW_E_OVERFLOW;
+        break;
+      }
+      uint64_t o = 0;
+      for (uint32_t j = 0; j < h_len[x]; j++) {
+        uint32_t v = h_ids[(size_t)x * CAPMAX + j];
+        float d = h_d[(size_t)x * CAPMAX + j];
+        if (v == h_nodes[i]) continue;   // filter(|(n,_)| *n != node)
+        if (!(d < threshold)) break;     // take_while(distance < threshold)
+        if (o == max_out) {
+          ph_set_error("threshold_nn: node %llu has more than max_out=%llu results", (unsigned long long)i,
+                       (unsigned long long)max_out);
+          rc = PHNSW_E_OVERFLOW;
+          break;
+        }
+        out_ids[i * max_out + o] = v;
+        out_d[i * max_out + o] = d;
+        o++;
+      }
+      out_len[i] = o;
+      for (; o < max_out; o++) {
+        out_ids[i * max_out + o] = PHNSW_EMPTY;
+        out_d[i * max_out + o] = PH_FMAX;
+      }
+    }
+  }
+  if (oid) hipFree(oid);
+  if (od) hipFree(od);
+  if (olen) hipFree(olen);
+  if (ostat) hipFree(ostat);
+  return rc;
 }

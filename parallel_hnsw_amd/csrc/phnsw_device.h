@@ -11,6 +11,7 @@
 #define ST_OK 0u
 #define ST_MISSING 4u
 #define ST_OVERFLOW 5u
+#define ST_CAPACITY 6u
 
 __device__ __forceinline__ uint32_t fkey(float d) {
   d += 0.0f;  // -0.0 -> +0.0 (OrderedFloat treats them as equal, src/types.rs:78-88)

@@ -52,7 +52,6 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   const uint64_t lt = lanemask_lt(lane);
   uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
   uint2 *ovf = a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
-  const uint32_t ef = a.ef;
 
   for (;;) {
     uint32_t q = 0;
@@ -61,7 +60,8 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     if (q >= a.nq) break;
 
     const uint32_t last_layer = a.n_layers - 1;
-    uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[q] : (a.qids ? a.qids[q] : 0u);
+    const uint32_t qnode = a.first_node + q;  // knn modes: the query is a node of the bottom layer
+    uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[qnode] : (a.qids ? a.qids[q] : 0u);
     Dist dist;
     if (a.queries && !a.knn_mode)
       dist.prepare_raw(a.dist, a.queries + (uint64_t)q * a.ldq, dist_lds, lane);
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
     uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
     uint32_t clen = 0;
+    uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
 
     if (!a.knn_mode) {
       // entry_vector + distance_from_entry  search.rs:101-111
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       if (a.knn_mode) {
         // pq.merge_pairs(&[(node, 0.0)])  lib.rs:917-918
         if (lane == 0) {
-          Qid[0] = q;
+          Qid[0] = qnode;
           Qd[0] = 0.0f;
-          atomicOr(&vis[q >> 5], 1u << (q & 31));
+          atomicOr(&vis[qnode >> 5], 1u << (qnode & 31));
         }
         qlen = 1;
       } else {
@@ -131,6 +132,28 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       }
       __syncthreads();
 
+      // Hnsw::threshold_nn (lib.rs:930-962, knn_mode == 2) calls closest_nodes repeatedly on a
+      // growing queue; everything else runs this block once
+      float thr_last = 0.0f;
+      uint32_t thr_last_size = 0;
+      for (;;) {
+      if (a.knn_mode == 2) {
+        if (!(thr_last < a.threshold && qlen > thr_last_size)) break;  // lib.rs:945
+        thr_last_size = qlen;
+        if (thr_last_size > 1 || n_hops > 0) {
+          // a fresh closest_nodes call: every queue entry is a seed again (lib.rs:182-187)
+#pragma unroll
+          for (int c = 0; c < CAPC; c++) {
+            uint32_t i = lane + 64u * c;
+            if (i < qlen) {
+              uint32_t nid = Qid[i] & IDM;
+              Qid[i] = nid;
+              atomicOr(&vis[nid >> 5], 1u << (nid & 31));
+            }
+          }
+          __syncthreads();
+        }
+      }
       // ---- closest_nodes  lib.rs:175-248
       uint32_t ovf_n = 0;
       uint32_t pd = a.probe_depth;
@@ -312,6 +335,17 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         }
       }
       wait_vm0();
+      if (a.knn_mode != 2) break;
+      thr_last = Qd[qlen - 1];  // pq.last().1  lib.rs:948
+      if (thr_last < a.threshold && qlen == ef) {  // pq.resize_capacity(capacity * 2)  lib.rs:949-951
+        if (ef * 2 > (uint32_t)CAP) {
+          err = ST_CAPACITY;
+          break;
+        }
+        ef *= 2;
+      }
+      }  // closest_nodes call loop
+      if (err != ST_OK) break;
 
       // ---- closest_vectors tail: NodeId -> VectorId, filter(include), take(count)  lib.rs:268-276
       const uint32_t candidate_count = (a.n_layers == 1 || li == last_layer) ? ef : a.upper;  // search.rs:122-126
@@ -407,7 +441,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       clen = 0;
     }
     // (candidates.iter().collect(), ..)  search.rs:139
-    const uint32_t ostride = a.out_stride ? a.out_stride : ef;
+    const uint32_t ostride = a.out_stride ? a.out_stride : a.ef;
     for (uint32_t i = lane; i < ostride; i += 64) {
       a.out_ids[(uint64_t)q * ostride + i] = i < clen ? Cid[i] : PH_EMPTY32;
       a.out_d[(uint64_t)q * ostride + i] = i < clen ? Cd[i] : PH_FMAX;
@@ -532,7 +566,7 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream) {
   const bool pq = ix->store->codes != nullptr;
   const size_t pq_lds = ph_pq_lds_bytes(ix->store);
-  int capc = pick_capc(a.ef), nv = pq ? 0 : pick_nv(a.dist.nv4);
+  int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
   ph_search_fn fn = (capc && (pq || nv)) ? pick_kernel(capc, nv) : nullptr;
   if (!fn) {
     ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);
@@ -543,7 +577,7 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   a.ovf = ws.ovf;
   a.ovf_cap = ws.ovf_cap;
   a.counter = ws.counter;
-  uint32_t slots = std::min<uint32_t>(ph_search_slots(a.ef, a.dist.nv4, pq, pq_lds), ws.n_slots);
+  uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
   PH_HIP(hipMemsetAsync(ws.counter, 0, 4, stream));

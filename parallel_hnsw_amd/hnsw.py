@@ -353,6 +353,30 @@ class Hnsw:
         nodes = self._layer(self.layer_count() - 1).nodes
         return [(int(nodes[i]), [(int(ids[i, j]), d[i, j]) for j in range(int(ln[i]))]) for i in range(n)]
 
+    def threshold_nn(self, threshold, probe_depth, initial_search_depth, max_out=64):
+        """Hnsw::threshold_nn  lib.rs:930-962 -> [(VectorId, [(VectorId, f32)])]"""
+        n = self.vector_count()
+        ids = np.empty((n, max_out), dtype=np.uint64)
+        d = np.empty((n, max_out), dtype=np.float32)
+        ln = np.zeros(n, dtype=np.uint64)
+        check(lib().phnsw_threshold_nn(self._h, threshold, probe_depth, initial_search_depth, max_out, _p(ids), _p(d),
+                                       _p(ln)))
+        nodes = self._layer(self.layer_count() - 1).nodes
+        return [(int(nodes[i]), [(int(ids[i, j]), d[i, j]) for j in range(int(ln[i]))]) for i in range(n)]
+
+    # -- Serializable (lib.rs:1688-1699, serialize.rs) -------------------------------
+    def serialize(self, path):
+        check(lib().phnsw_index_serialize(self._h, str(path).encode()))
+
+    @classmethod
+    def deserialize(cls, path, store):
+        """Hnsw::deserialize(path, params): `store` plays the role of the comparator params"""
+        h = C.c_void_p()
+        check(lib().phnsw_index_deserialize(store._h, str(path).encode(), C.byref(h)))
+        bp = BuildParams()
+        check(lib().phnsw_index_build_params(h, C.byref(bp)))
+        return cls(store, h, bp)
+
     def kernel_ms(self):
         ms = C.c_float()
         check(lib().phnsw_last_search_kernel_ms(self._h, C.byref(ms)))

@@ -1,0 +1,109 @@
+"""SURVEY section 8 'next' rows on the GPU path: f1 on-disk format (serialize.rs), f3 bulk
+knn / threshold_nn (lib.rs:905-962)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parallel_hnsw_amd as ph
+from helpers import EMPTY, load, toy_vectors
+
+pytestmark = pytest.mark.gpu
+TOY = load("toy_index.json")
+
+
+def fixture_graph(entry=0):
+    g = TOY["test_generation"]
+    data = toy_vectors()
+    store = ph.VectorStore(data, metric=ph.METRIC_ONE_MINUS_DOT)
+    top = (np.array([entry], dtype=np.uint64), np.full((1, 3), EMPTY, dtype=np.uint64))
+    bottom = (np.arange(9, dtype=np.uint64), np.array(g["neighbors"], dtype=np.uint64))
+    return store, ph.Hnsw.from_layers(store, [top, bottom])
+
+
+@pytest.mark.parametrize("entry", [0, 3])
+def test_threshold_nn_golden(entry):
+    """reference test_threshold_nn (lib.rs:2379-2420) on the reference's own test graph"""
+    store, h = fixture_graph(entry)
+    t = TOY["test_threshold_nn"]
+    res = h.threshold_nn(t["threshold"], t["probe_depth"], t["initial_search_depth"])
+    for (v, got), exp in zip(res, t["expect"]):
+        assert [g[0] for g in got] == [e[0] for e in exp], v
+        np.testing.assert_allclose([g[1] for g in got], [e[1] for e in exp], rtol=1e-5, atol=1e-7)
+
+
+def test_knn_and_threshold_nn_parity_large():
+    n, dim = 4000, 32
+    rows = oracle.synth_rows(0, n, dim)
+    oix = oracle.Index.generate(rows, np.arange(n), oracle.default_build_params(seed=2), dim=dim,
+                                sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim])
+    g = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)])
+    ki, kd, kl = oix.knn(5, 2)
+    res = g.knn(5, 2)
+    for i, (v, got) in enumerate(res):
+        assert [x[0] for x in got] == [int(x) for x in ki[i, :int(kl[i])]]
+        assert [np.float32(x[1]).view(np.uint32) for x in got] == [x.view(np.uint32) for x in kd[i, :int(kl[i])]]
+    # radius query with queue doubling (initial depth 4 forces several resize_capacity steps)
+    thr = np.float32(0.33)
+    ti, td, tl = oix.threshold_nn(thr, 2, 4, max_out=256)
+    res = g.threshold_nn(float(thr), 2, 4, max_out=256)
+    assert int(tl.max()) > 8  # the queue really grew
+    for i, (v, got) in enumerate(res):
+        assert [x[0] for x in got] == [int(x) for x in ti[i, :int(tl[i])]], i
+        assert [np.float32(x[1]).view(np.uint32) for x in got] == [x.view(np.uint32) for x in td[i, :int(tl[i])]]
+
+
+def test_serialize_layout_and_roundtrip(tmp_path):
+    """serialize_hnsw / deserialize_hnsw  serialize.rs:33-209"""
+    n, dim = 1500, 16
+    rows = oracle.synth_rows(0, n, dim)
+    store = ph.VectorStore(rows[:, :dim])
+    bp = ph.BuildParameters(order=6, neighborhood_size=8, zero_layer_neighborhood_size=16, seed=3)
+    h = ph.Hnsw.generate(store, np.arange(n), bp)
+    p = tmp_path / "index"
+    h.serialize(p)
+    L = h.layer_count()
+    meta = json.load(open(p / "meta"))
+    assert meta["layer_count"] == L
+    b = meta["build_parameters"]
+    assert list(b) == ["order", "zero_layer_neighborhood_size", "neighborhood_size", "optimization",
+                       "initial_partition_search"]  # serde field order (parameters.rs:42-48)
+    assert (b["order"], b["zero_layer_neighborhood_size"], b["neighborhood_size"]) == (6, 16, 8)
+    assert b["optimization"]["search"] == {"number_of_candidates": 300, "upper_layer_candidate_count": 300,
+                                           "probe_depth": 2}
+    raw = open(p / "meta").read()
+    assert '"promotion_threshold":0.01,' in raw and '"promotion_proportion":1.0,' in raw  # serde_json f32 text
+    assert (p / "comparator").is_dir()
+    for lft in range(L):
+        number = L - lft - 1  # layers are numbered from the bottom (serialize.rs:67)
+        lay = h._layer(lft)
+        lm = json.load(open(p / ("layer.meta.%d" % number)))
+        assert lm == {"node_count": lay.node_count(), "neighborhood_size": lay.neighborhood_size}
+        nodes = np.fromfile(p / ("layer.nodes.%d" % number), dtype="<u8")
+        nb = np.fromfile(p / ("layer.neighbors.%d" % number), dtype="<u8")
+        np.testing.assert_array_equal(nodes, lay.nodes)
+        np.testing.assert_array_equal(nb.reshape(lay.neighbors.shape), lay.neighbors)
+        assert (nb == EMPTY).sum() == (lay.neighbors == EMPTY).sum()
+    h2 = ph.Hnsw.deserialize(p, store)
+    assert h2.layer_count() == L
+    assert h2.build_parameters.order == 6 and h2.build_parameters.neighborhood_size == 8
+    q = oracle.synth_rows(2 ** 32, 50, dim)[:, :dim]
+    a = h.search_batch(queries=q, sp=ph.SearchParameters(64, 64, 2))
+    c = h2.search_batch(queries=q, sp=ph.SearchParameters(64, 64, 2))
+    np.testing.assert_array_equal(a[0], c[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+    # a layer stack written by "the crate" (here: by hand) is adopted as well
+    os.remove(p / "comparator" / "vectors.f32")
+    h3 = ph.Hnsw.deserialize(p, store)
+    assert h3.layer_count() == L
+    # no comparator entry => Index not found (serialize.rs:144-146)
+    import shutil
+    shutil.rmtree(p / "comparator")
+    with pytest.raises(ph.PhnswError) as e:
+        ph.Hnsw.deserialize(p, store)
+    assert "not found" in str(e.value).lower()
+    with pytest.raises(ph.PhnswError):
+        ph.Hnsw.deserialize(tmp_path / "nothing-here", store)
