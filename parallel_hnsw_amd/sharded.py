@@ -47,6 +47,8 @@ class TorchComm:
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
         self.dist.all_gather_into_tensor(out, src, group=self.group)
         self.bytes_gathered += out.numel() * out.element_size()
+        if t.is_cuda and not staged:
+            torch.cuda.synchronize(t.device)  # libphnsw reads the result outside torch's stream bookkeeping
         return out.to(t.device) if staged else out
 
     def all_reduce_sum(self, values, device):
