@@ -78,6 +78,7 @@ typedef struct {
   phnsw_search_params initial_partition_search;
   uint64_t seed;            /* replaces thread_rng() of lib.rs:832 */
   uint64_t max_link_rounds; /* 0 = loop until improvement < neighborhood_threshold (lib.rs:1527) */
+  uint64_t promote;         /* 1 (default) = promote_at_layer as the reference (lib.rs:1575-1589); 0 = never */
 } phnsw_build_params;
 
 void phnsw_default_search_params(phnsw_search_params *sp);
@@ -141,6 +142,12 @@ int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_pro
 /* Hnsw::improve_neighbors_upto  src/lib.rs:1515-1544 ; last_recall NaN = None */
 int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
                                  float last_recall, float *out_recall);
+/* Hnsw::promote_at_layer  src/lib.rs:1273-1427 ; *out_promoted = the bool it returns */
+int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,
+                           int *out_promoted);
+/* Hnsw::discover_unreachable_vectors  src/lib.rs:1002-1037 ; out sized node_count of the layer */
+int phnsw_discover_unreachable(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                               uint64_t *out_vecs, uint64_t *out_count);
 /* Hnsw::stochastic_recall_at  src/lib.rs:1463-1499 */
 int phnsw_stochastic_recall_at(phnsw_index *ix, uint32_t layer_from_top,
                                const phnsw_optimization_params *op, float *out_recall);

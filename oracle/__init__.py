@@ -43,7 +43,7 @@ class BuildParams(C.Structure):
     _fields_ = [("order", C.c_uint64), ("zero_layer_neighborhood_size", C.c_uint64),
                 ("neighborhood_size", C.c_uint64), ("optimization", OptParams),
                 ("initial_partition_search", SearchParams), ("seed", C.c_uint64),
-                ("max_link_rounds", C.c_uint64)]
+                ("max_link_rounds", C.c_uint64), ("promote", C.c_uint64)]
 
 
 class Store(C.Structure):
@@ -134,6 +134,12 @@ def lib():
         L.orc_improve_neighbors_upto.argtypes = [vp, u32, C.POINTER(BuildParams), f32, i32]
         L.orc_improve_index.restype = f32
         L.orc_improve_index.argtypes = [vp, C.POINTER(BuildParams), i32]
+        L.orc_promote_at_layer.restype = i32
+        L.orc_promote_at_layer.argtypes = [vp, u32, C.POINTER(BuildParams), i32]
+        L.orc_extend_layer.restype = i32
+        L.orc_extend_layer.argtypes = [vp, u32, vp, u64]
+        L.orc_discover_unreachable.restype = u64
+        L.orc_discover_unreachable.argtypes = [vp, u32, SearchParams, C.POINTER(C.POINTER(u64)), i32]
         L.orc_check_layer_invariants.restype = i32
         L.orc_check_layer_invariants.argtypes = [vp]
         L.orc_mix64.restype = u64
@@ -424,6 +430,20 @@ class Index:
         if rc:
             raise RuntimeError("orc_pq_search_batch rc=%d" % rc)
         return (ids, d, ln, st) if stats else (ids, d, ln)
+
+    def promote_at_layer(self, layer_from_top, bp, threads=8):
+        return lib().orc_promote_at_layer(self.h, layer_from_top, C.byref(bp), threads)
+
+    def extend_layer(self, layer_from_top, vecs):
+        v = np.ascontiguousarray(vecs, dtype=np.uint64)
+        return lib().orc_extend_layer(self.h, layer_from_top, _p(v), len(v))
+
+    def discover_unreachable(self, layer_from_top, sp, threads=8):
+        out = C.POINTER(C.c_uint64)()
+        n = lib().orc_discover_unreachable(self.h, layer_from_top, SearchParams(*sp), C.byref(out), threads)
+        res = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy()
+        C.CDLL(None).free(out)
+        return res
 
     def check_layer_invariants(self):
         return lib().orc_check_layer_invariants(self.h)

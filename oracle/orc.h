@@ -102,6 +102,7 @@ typedef struct {
   orc_search_params initial_partition_search;
   uint64_t seed;           /* replaces thread_rng (lib.rs:832) */
   uint64_t max_link_rounds; /* 0 = reference loop (until improvement < threshold) */
+  uint64_t promote;         /* 1 = promote_at_layer as the reference does (lib.rs:1580); 0 = skip */
 } orc_build_params;
 void orc_default_build_params(orc_build_params *bp);
 
@@ -188,6 +189,13 @@ float orc_improve_neighbors_upto(orc_index *ix, uint32_t upto, const orc_build_p
                                  float last_recall_or_nan, int threads);
 /* improve_index lib.rs:1664-1686 minus promotion */
 float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads);
+/* discover_unreachable_vectors lib.rs:1002-1037 ; returns count, *out malloc'd (caller frees) */
+uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t layer_from_top, orc_search_params sp,
+                                  uint64_t **out, int threads);
+/* promote_at_layer lib.rs:1273-1427 (deterministic tie order) ; 1 = promoted */
+int orc_promote_at_layer(orc_index *ix, uint32_t layer_from_top, const orc_build_params *bp, int threads);
+/* extend_layer lib.rs:1039-1068 (layer counted from the top here) */
+int orc_extend_layer(orc_index *ix, uint32_t layer_from_top, const uint64_t *vecs, uint64_t count);
 /* assert_layer_invariants search.rs:142-171 ; 0 = ok */
 int orc_check_layer_invariants(const orc_index *ix);
 

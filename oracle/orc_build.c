@@ -35,6 +35,7 @@ void orc_default_build_params(orc_build_params *bp) {
   bp->initial_partition_search.probe_depth = 2;
   bp->seed = 0;
   bp->max_link_rounds = 0;
+  bp->promote = 1; /* the reference always tries promote_at_layer (lib.rs:1575-1580) */
 }
 
 /* ---------------------------------------------------------------- partitions */
@@ -615,10 +616,271 @@ float orc_improve_neighbors_upto(orc_index *ix, uint32_t upto, const orc_build_p
   return last_recall;
 }
 
-/* improve_index_at  src/lib.rs:1546-1603 with promote_at_layer treated as "did not
- * promote" (promotion = SURVEY section 8 row f2, out of scope) */
-static float improve_index_at(orc_index *ix, uint32_t lft, const orc_build_params *bp, int threads) {
+/* ---------------------------------------------------------------- promotion */
+
+/* match_within_epsilon  src/search.rs:173-187 */
+static int match_within_epsilon(uint64_t vector, const uint64_t *ids, const float *d, uint64_t len) {
+  int found = 0;
+  const float epsilon = 1e-5f;
+  for (uint64_t k = 0; k < len; k++) {
+    if (fabsf(d[k]) < epsilon) {
+      if (ids[k] == vector) found = 1;
+    } else
+      break;
+  }
+  return found;
+}
+
+/* discover_unreachable_vectors  src/lib.rs:1002-1037 */
+uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t **out,
+                                  int threads) {
+  const orc_layer *cur = &ix->layers[lft];
+  const orc_layer *above = lft ? &ix->layers[lft - 1] : NULL;
+  uint64_t n = cur->node_count;
+  uint8_t *flag = (uint8_t *)calloc(n, 1);
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+    orc_scratch *sc = orc_scratch_new(ix, 0);
+    uint64_t cap = sp.number_of_candidates;
+    uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    float *od = (float *)malloc(sizeof(float) * cap);
+#pragma omp for schedule(dynamic, 16)
+    for (uint64_t i = 0; i < n; i++) {
+      uint64_t vector = cur->nodes[i], len = 0;
+      orc_search_sc(ix, NULL, vector, sp, lft + 1, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
+      int in_matches = match_within_epsilon(vector, oi, od, len);
+      if (!in_matches && (!above || orc_layer_get_node(above, vector) == ORC_EMPTY)) flag[i] = 1;
+    }
+    free(oi);
+    free(od);
+    orc_scratch_free(sc);
+  }
+  uint64_t cnt = 0;
+  for (uint64_t i = 0; i < n; i++) cnt += flag[i];
+  uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t) * (cnt ? cnt : 1));
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < n; i++)
+    if (flag[i]) v[c++] = cur->nodes[i];
+  free(flag);
+  *out = v;
+  return cnt;
+}
+
+/* extend_layer  src/lib.rs:1039-1068 with generate_node_maps :1767-1812,
+ * copy_old_neighborhoods_into_layer :1737-1765, initialize_new_neighborhoods :1727-1735 */
+int orc_extend_layer(orc_index *ix, uint32_t lft, const uint64_t *vecs_in, uint64_t count) {
+  orc_layer *L = &ix->layers[lft];
+  uint64_t W = L->neighborhood_size, n_old = L->node_count, n_new = n_old + count;
+  uint64_t *vecs = (uint64_t *)malloc(sizeof(uint64_t) * (count ? count : 1));
+  memcpy(vecs, vecs_in, sizeof(uint64_t) * count);
+  qsort(vecs, count, sizeof(uint64_t), u64_cmp);
+  uint64_t *nodes = (uint64_t *)malloc(sizeof(uint64_t) * n_new);
+  uint64_t *old_map = (uint64_t *)malloc(sizeof(uint64_t) * (n_old ? n_old : 1));
+  uint8_t *is_new = (uint8_t *)calloc(n_new, 1);
+  uint64_t a = 0, b = 0, o = 0;
+  while (a < n_old || b < count) {
+    if (b >= count || (a < n_old && L->nodes[a] < vecs[b])) {
+      old_map[a] = o;
+      nodes[o++] = L->nodes[a++];
+    } else {
+      if (a < n_old && L->nodes[a] == vecs[b]) { /* panic!("tried to insert vector that already exists") */
+        free(vecs); free(nodes); free(old_map); free(is_new);
+        return -5;
+      }
+      is_new[o] = 1;
+      nodes[o++] = vecs[b++];
+    }
+  }
+  uint64_t *nb = (uint64_t *)malloc(sizeof(uint64_t) * n_new * W);
+  for (uint64_t i = 0; i < n_new * W; i++) nb[i] = ORC_EMPTY;
+  for (uint64_t i = 0; i < n_old; i++)
+    for (uint64_t k = 0; k < W; k++) {
+      uint64_t x = L->neighbors[i * W + k];
+      nb[old_map[i] * W + k] = x == ORC_EMPTY ? ORC_EMPTY : old_map[x];
+    }
+  free(L->nodes);
+  free(L->neighbors);
+  L->nodes = nodes;
+  L->neighbors = nb;
+  L->node_count = n_new;
+  free(vecs); free(old_map); free(is_new);
+  return 0;
+}
+
+typedef struct {
+  uint64_t node;
+  uint64_t count;
+} histo_t;
+static int histo_cmp(const void *x, const void *y) {
+  const histo_t *a = (const histo_t *)x, *b = (const histo_t *)y;
+  if (a->count != b->count) return a->count < b->count ? -1 : 1; /* sort_by_key(count)  :1228 */
+  return a->node < b->node ? -1 : (a->node > b->node ? 1 : 0);  /* HashMap order in the reference */
+}
+
+/* filter_promotion_candidates  src/lib.rs:1176-1271.  Every unreachable vector of layer
+ * `lft` is absent from the layer above (discover_unreachable_vectors :1027-1029), so by the
+ * nesting invariant its discover_order_from_top is `lft` and there is one histogram. */
+static uint64_t filter_promotion_candidates(orc_index *ix, uint32_t lft, const uint64_t *vecs, uint64_t nv,
+                                            orc_search_params sp, uint64_t **out, int threads) {
+  *out = NULL;
+  if (lft == 0) return 0; /* :1182-1184 */
+  const orc_store *S = &ix->store;
+  const orc_layer *L = &ix->layers[lft];
+  uint64_t W = L->neighborhood_size;
+  uint64_t *count = (uint64_t *)calloc(L->node_count, sizeof(uint64_t));
+  for (uint64_t k = 0; k < nv; k++) { /* histogramming :1190-1223 */
+    uint64_t node = orc_layer_get_node(L, vecs[k]);
+    uint64_t fin = orc_final_neighbor_idx(W, L->neighbors, node);
+    for (uint64_t x = node * W; x < fin; x++) {
+      uint64_t nbr = L->neighbors[x];
+      uint64_t nvct = L->nodes[nbr];
+      if (bsearch(&nvct, vecs, nv, sizeof(uint64_t), u64_cmp)) count[nbr]++;
+    }
+  }
+  uint64_t nh = 0;
+  for (uint64_t i = 0; i < L->node_count; i++) nh += count[i] != 0;
+  histo_t *h = (histo_t *)malloc(sizeof(histo_t) * (nh ? nh : 1));
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < L->node_count; i++)
+    if (count[i]) {
+      h[c].node = i;
+      h[c].count = count[i];
+      c++;
+    }
+  free(count);
+  qsort(h, nh, sizeof(histo_t), histo_cmp);
+  uint64_t *sel = (uint64_t *)malloc(sizeof(uint64_t) * (nh ? nh : 1));
+  float *radius = (float *)malloc(sizeof(float) * (nh ? nh : 1));
+  uint64_t ns = 0;
+  orc_scratch *sc = orc_scratch_new(ix, 0);
+  uint64_t cap = sp.number_of_candidates;
+  uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+  float *od = (float *)malloc(sizeof(float) * cap);
+  while (nh) { /* while let Some((node, _)) = histogram.pop()  :1243 */
+    uint64_t vec = L->nodes[h[--nh].node];
+    int covered = 0;
+    orc_query_prepare(S, sc, NULL, vec);
+    for (uint64_t k = 0; k < ns && !covered; k++) /* compare_vec(Stored(v), Stored(vec)) < radius  :1244-1249 */
+      if (orc_query_dist(S, sc, sel[k]) < radius[k]) covered = 1;
+    if (covered) continue;
+    uint64_t len = 0;
+    /* self.search_upto(Stored(vec), search_parameters, layer_from_top)  :1254-1258 */
+    orc_search_sc(ix, NULL, vec, sp, lft, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
+    sel[ns] = vec;
+    radius[ns] = len ? od[0] : 0.0f; /* result[0].1 */
+    ns++;
+  }
+  orc_scratch_free(sc);
+  free(oi); free(od); free(h); free(radius);
+  (void)threads;
+  *out = sel;
+  return ns;
+}
+
+static uint32_t partitions_from_bottom(uint64_t total, uint64_t order, uint64_t *out, uint32_t max_out);
+static orc_index *generate_impl(const float *rows, uint64_t n_store, uint32_t dim, uint32_t ld, int metric, int sum_mode,
+                                const orc_store *pq_from, const uint64_t *vids, uint64_t n,
+                                const orc_build_params *bp, int threads);
+
+/* promote_at_layer  src/lib.rs:1273-1427 */
+int orc_promote_at_layer(orc_index *ix, uint32_t lft, const orc_build_params *bp, int threads) {
+  float max_proportion = bp->optimization.promotion_proportion;
+  uint64_t *vecs = NULL;
+  uint64_t nv = orc_discover_unreachable(ix, lft, bp->optimization.search, &vecs, threads);
+  if (nv == 0) {
+    free(vecs);
+    return 0;
+  }
+  if (max_proportion < 1.0f) { /* :1288-1294 */
+    nv = (uint64_t)((float)nv * max_proportion);
+    if (nv == 0) {
+      free(vecs);
+      return 0;
+    }
+  }
+  uint64_t *sel = NULL;
+  uint64_t ns = filter_promotion_candidates(ix, lft, vecs, nv, bp->optimization.search, &sel, threads);
+  free(vecs);
+  if (lft == 0 || ns == 0) { /* order_vecs empty (or an empty selection): nothing to extend, still "true" */
+    free(sel);
+    return 1;
+  }
+  /* the else branch of :1332-1420 (layer_from_top = lft >= 1) */
+  uint64_t sizes[128], new_sizes[128], promo[128];
+  uint32_t nsz = lft;
+  for (uint32_t i = 0; i < nsz; i++) sizes[i] = ix->layers[lft - 1 - i].node_count; /* reversed: [0] = just above */
+  uint32_t nnew = partitions_from_bottom(sizes[0] + ns, bp->order, new_sizes, 128);
+  while (nnew < nsz) new_sizes[nnew++] = 0; /* :1345-1349 */
+  uint32_t retop_upto = nnew - nsz;
+  uint32_t npromo = nsz;
+  for (uint32_t i = 0; i < nsz; i++) promo[i] = new_sizes[i] > sizes[i] ? new_sizes[i] - sizes[i] : 0;
+  uint32_t offset = 0;
+  if (retop_upto != 0) { /* :1361-1397 */
+    uint32_t retop_index = npromo - retop_upto;
+    uint64_t into_top = promo[retop_index];
+    if (into_top > ns) into_top = ns;
+    npromo = retop_index;
+    const orc_layer *T = &ix->layers[retop_upto - 1];
+    uint64_t nt = T->node_count + into_top;
+    uint64_t *top = (uint64_t *)malloc(sizeof(uint64_t) * nt);
+    memcpy(top, T->nodes, sizeof(uint64_t) * T->node_count);
+    memcpy(top + T->node_count, sel, sizeof(uint64_t) * into_top);
+    qsort(top, nt, sizeof(uint64_t), u64_cmp);
+    uint64_t u = 0;
+    for (uint64_t k = 0; k < nt; k++)
+      if (k == 0 || top[k] != top[k - 1]) top[u++] = top[k]; /* dedup */
+    orc_build_params nbp = *bp;
+    nbp.zero_layer_neighborhood_size = bp->neighborhood_size; /* :1377-1379 */
+    nbp.seed = bp->seed + 0x51ED270B9F3ULL + ix->layer_count;  /* thread_rng in the reference */
+    orc_index *nt_ix = generate_impl(ix->store.rows, ix->store.n, ix->store.dim, ix->store.ld, ix->store.metric,
+                                     ix->store.sum_mode, &ix->store, top, u, &nbp, threads);
+    free(top);
+    if (!nt_ix) {
+      free(sel);
+      return -1;
+    }
+    uint32_t new_top_len = nt_ix->layer_count;
+    uint32_t keep = ix->layer_count - retop_upto;
+    orc_layer *nl = (orc_layer *)malloc(sizeof(orc_layer) * (new_top_len + keep));
+    memcpy(nl, nt_ix->layers, sizeof(orc_layer) * new_top_len);
+    memcpy(nl + new_top_len, ix->layers + retop_upto, sizeof(orc_layer) * keep);
+    for (uint32_t i = 0; i < retop_upto; i++) {
+      free(ix->layers[i].nodes);
+      free(ix->layers[i].neighbors);
+    }
+    free(ix->layers);
+    ix->layers = nl;
+    ix->layer_count = new_top_len + keep;
+    free(nt_ix->layers); /* the layer structs moved; free only the shell */
+    nt_ix->layers = NULL;
+    nt_ix->layer_count = 0;
+    orc_index_free(nt_ix);
+    offset = new_top_len;
+  }
+  /* promotion_sizes.reverse(); extend each remaining layer above  :1398-1412 */
+  for (uint32_t i = 0; i < npromo; i++) {
+    uint64_t size = promo[npromo - 1 - i];
+    uint32_t cur = offset + i;
+    const orc_layer *L = &ix->layers[cur];
+    uint64_t *tp = (uint64_t *)malloc(sizeof(uint64_t) * (ns ? ns : 1));
+    uint64_t c = 0;
+    for (uint64_t k = 0; k < ns && c < size; k++)
+      if (orc_layer_get_node(L, sel[k]) == ORC_EMPTY) tp[c++] = sel[k];
+    int rc = orc_extend_layer(ix, cur, tp, c);
+    free(tp);
+    if (rc) {
+      free(sel);
+      return -1;
+    }
+  }
+  free(sel);
+  return 1;
+}
+
+/* improve_index_at  src/lib.rs:1546-1603; *lft may grow when promotion adds layers */
+static float improve_index_at(orc_index *ix, uint32_t *lft_io, const orc_build_params *bp, int threads) {
   const orc_opt_params *op = &bp->optimization;
+  uint32_t lft = *lft_io;
   float recall = orc_stochastic_recall_at(ix, lft, op, threads);
   float improvement = 1.0f;
   int bailout = 1;
@@ -626,35 +888,57 @@ static float improve_index_at(orc_index *ix, uint32_t lft, const orc_build_param
     float last = recall;
     uint32_t cur = 0;
     while (cur <= lft && bailout != 0) {
+      uint32_t layer_count = ix->layer_count;
       recall = orc_improve_neighbors_upto(ix, cur + 1, bp, NAN, threads);
+      if (recall == 1.0f) { /* :1569-1572 */
+        cur++;
+        continue;
+      }
+      if (bp->promote) {
+        int pr = orc_promote_at_layer(ix, cur, bp, threads); /* :1575 */
+        if (pr > 0) {
+          uint32_t delta = ix->layer_count - layer_count;
+          cur += delta;
+          lft += delta;
+          recall = orc_improve_neighbors_upto(ix, cur + 1, bp, recall, threads); /* :1586-1587 */
+        }
+      }
       cur++;
     }
     bailout--;
     improvement = recall - last;
   }
+  *lft_io = lft;
   return recall;
 }
 
 /* improve_index  src/lib.rs:1664-1686 */
 float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads) {
   float recall = orc_stochastic_recall_at(ix, ix->layer_count - 1, &bp->optimization, threads);
-  for (uint32_t lft = 0; lft < ix->layer_count; lft++) recall = improve_index_at(ix, lft, bp, threads);
+  uint32_t lft = 0;
+  while (lft < ix->layer_count) {
+    recall = improve_index_at(ix, &lft, bp, threads);
+    lft++;
+  }
   return recall;
 }
 
 /* Hnsw::generate  src/lib.rs:825-893 */
-orc_index *orc_generate(const float *rows, uint64_t n_store, uint32_t dim, uint32_t ld, int metric,
-                        int sum_mode, const uint64_t *vids, uint64_t n, const orc_build_params *bp,
-                        int threads) {
+static orc_index *generate_impl(const float *rows, uint64_t n_store, uint32_t dim, uint32_t ld, int metric, int sum_mode,
+                                const orc_store *pq_from, const uint64_t *vids, uint64_t n,
+                                const orc_build_params *bp, int threads) {
   if (n == 0 || bp->order < 2) return NULL; /* assert!(total_size > 0) :837 */
   orc_index *ix = orc_index_new(rows, n_store, dim, ld, metric, sum_mode);
   if (!ix) return NULL;
+  if (pq_from && pq_from->codes)
+    orc_index_set_pq(ix, pq_from->codes, pq_from->codebook, pq_from->pq_m, pq_from->pq_ksub, pq_from->pq_dsub);
   uint64_t *vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
   memcpy(vs, vids, sizeof(uint64_t) * n);
   orc_shuffle_u64(vs, n, bp->seed); /* vs.shuffle(&mut thread_rng()) :832-833 */
   uint64_t parts[128];
   uint32_t np = orc_calculate_partitions(n, bp->order, parts, 128);
-  for (uint32_t i = 0; i < np; i++) {
+  uint32_t i = 0;
+  while (i != np) { /* :854-890 */
     uint64_t length = parts[i] < n ? parts[i] : n; /* :858-860 */
     uint32_t level = np - i - 1;
     uint64_t W = level == 0 ? bp->zero_layer_neighborhood_size : bp->neighborhood_size;
@@ -663,10 +947,28 @@ orc_index *orc_generate(const float *rows, uint64_t n_store, uint32_t dim, uint3
       free(vs);
       return NULL;
     }
+    uint32_t old_count = ix->layer_count;
     orc_improve_index(ix, bp, threads); /* :877 */
+    uint32_t delta = ix->layer_count - old_count;
+    if (delta > 0) { /* new layers were added: fix the partitions  :880-887 */
+      uint64_t suffix[128];
+      uint32_t ns = np - (i + 1);
+      memcpy(suffix, parts + i + 1, sizeof(uint64_t) * ns);
+      for (uint32_t k = 0; k < ix->layer_count; k++) parts[k] = ix->layers[k].node_count;
+      memcpy(parts + ix->layer_count, suffix, sizeof(uint64_t) * ns);
+      np = ix->layer_count + ns;
+      i += delta;
+    }
+    i++;
   }
   free(vs);
   return ix;
+}
+
+orc_index *orc_generate(const float *rows, uint64_t n_store, uint32_t dim, uint32_t ld, int metric,
+                        int sum_mode, const uint64_t *vids, uint64_t n, const orc_build_params *bp,
+                        int threads) {
+  return generate_impl(rows, n_store, dim, ld, metric, sum_mode, NULL, vids, n, bp, threads);
 }
 
 /* assert_layer_invariants  src/search.rs:142-171 */

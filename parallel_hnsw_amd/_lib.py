@@ -35,7 +35,7 @@ class BuildParams(C.Structure):
     _fields_ = [("order", C.c_uint64), ("zero_layer_neighborhood_size", C.c_uint64),
                 ("neighborhood_size", C.c_uint64), ("optimization", OptimizationParams),
                 ("initial_partition_search", SearchParams), ("seed", C.c_uint64),
-                ("max_link_rounds", C.c_uint64)]
+                ("max_link_rounds", C.c_uint64), ("promote", C.c_uint64)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64)
@@ -62,6 +62,8 @@ SYMBOLS = {
     "phnsw_link_layer": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, C.POINTER(_u64)]),
     "phnsw_improve_index": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, C.POINTER(_f32)]),
     "phnsw_improve_neighbors_upto": (_i32, [_vp, _u32, C.POINTER(BuildParams), _f32, C.POINTER(_f32)]),
+    "phnsw_promote_at_layer": (_i32, [_vp, _u32, C.POINTER(BuildParams), C.POINTER(_i32)]),
+    "phnsw_discover_unreachable": (_i32, [_vp, _u32, C.POINTER(SearchParams), _vp, C.POINTER(_u64)]),
     "phnsw_stochastic_recall_at": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), C.POINTER(_f32)]),
     "phnsw_index_destroy": (None, [_vp]),
     "phnsw_index_layer_count": (_u32, [_vp]),

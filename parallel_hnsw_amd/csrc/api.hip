@@ -56,6 +56,7 @@ extern "C" void phnsw_default_build_params(phnsw_build_params *bp) {
   bp->initial_partition_search.probe_depth = 2;
   bp->seed = 0;
   bp->max_link_rounds = 0;
+  bp->promote = 1;  // the reference always tries promote_at_layer (lib.rs:1575-1580)
 }
 
 static int use_device(int device) {
@@ -504,7 +505,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
-                     uint32_t *out_hit, float threshold, uint32_t first_node) {
+                     uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -523,6 +524,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.out_hit = out_hit;
   a.threshold = threshold;
   a.first_node = first_node;
+  a.hit_eps = hit_eps;
   a.cap_max = knn_mode == 2 ? out_stride : 0;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
   int rc = ph_workspace_ensure(ix, mix->ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));

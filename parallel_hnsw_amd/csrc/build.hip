@@ -1044,9 +1044,257 @@ static int improve_neighbors_upto_impl(phnsw_index *ix, uint32_t upto, const phn
   return 0;
 }
 
-// improve_index_at  lib.rs:1546-1603 with promote_at_layer treated as "did not promote"
-static int improve_index_at_impl(phnsw_index *ix, uint32_t lft, const phnsw_build_params *bp, float *out) {
+// ------------------------------------------------------------------ promotion (lib.rs:1002-1068, 1167-1427)
+
+static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                      phnsw_progress_cb cb, void *user, phnsw_index **out);
+
+// discover_unreachable_vectors  lib.rs:1002-1037: nodes of layer `lft` that a search over
+// layers[0..=lft] does not return among its leading |d| < 1e-5 results
+// (match_within_epsilon search.rs:173-187) and that are not in the layer above
+static int discover_unreachable_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp,
+                                     std::vector<uint32_t> &out) {
+  if (lft >= ix->layers.size()) {
+    ph_set_error("discover_unreachable: layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  PhLayerHost &L = ix->layers[lft];
+  PhTimer tm("discover_unreachable", L.n_nodes);
+  uint32_t n = L.n_nodes;
+  DevBuf<uint32_t> ids, len, hit;
+  DevBuf<float> d;
+  PH_TRY(ids.alloc(n));
+  PH_TRY(d.alloc(n));
+  PH_TRY(len.alloc(n));
+  PH_TRY(hit.alloc(n));
+  // search_stored with the epsilon form of the hit flag
+  {
+    DevBuf<uint32_t> status;
+    PH_TRY(status.alloc(n));
+    uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+    bool done = false;
+    for (int attempt = 0; attempt < 3 && !done; attempt++) {
+      PH_TRY(ph_search_device(ix, nullptr, 0, L.nodes, n, sp, lft + 1, nullptr, ids.p, d.p, len.p, nullptr, status.p,
+                              ovf_cap, 0, 0, 1, hit.p, 0.f, 0, 1e-5f));
+      PH_HIP(hipDeviceSynchronize());
+      std::vector<uint32_t> hs(n);
+      PH_HIP(hipMemcpy(hs.data(), status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      bool overflow = false;
+      for (uint32_t x : hs) {
+        if (x == 4) {
+          ph_set_error("discover_unreachable: layers are not nested");
+          return PHNSW_E_MISSING_NODE;
+        }
+        overflow |= x == 5;
+      }
+      done = !overflow;
+      ovf_cap *= 8;
+    }
+    if (!done) {
+      ph_set_error("discover_unreachable: frontier spill overflow");
+      return PHNSW_E_OVERFLOW;
+    }
+  }
+  std::vector<uint32_t> h(n), nodes(n), above;
+  PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PH_HIP(hipMemcpy(nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (lft > 0) {
+    above.resize(ix->layers[lft - 1].n_nodes);
+    PH_HIP(hipMemcpy(above.data(), ix->layers[lft - 1].nodes, above.size() * 4, hipMemcpyDeviceToHost));
+  }
+  out.clear();
+  for (uint32_t i = 0; i < n; i++)
+    if (!h[i] && (lft == 0 || !std::binary_search(above.begin(), above.end(), nodes[i]))) out.push_back(nodes[i]);
+  return 0;
+}
+
+// extend_layer  lib.rs:1039-1068 (generate_node_maps :1767-1812, copy_old_neighborhoods :1737-1765,
+// initialize_new_neighborhoods :1727-1735): integer renumbering on the host
+static int extend_layer_impl(phnsw_index *ix, uint32_t lft, std::vector<uint32_t> vecs) {
+  PhLayerHost &L = ix->layers[lft];
+  const uint32_t W = L.W, n_old = L.n_nodes;
+  std::sort(vecs.begin(), vecs.end());
+  std::vector<uint32_t> old_nodes(n_old), old_nb((size_t)n_old * W);
+  std::vector<float> old_d;
+  PH_HIP(hipMemcpy(old_nodes.data(), L.nodes, (size_t)n_old * 4, hipMemcpyDeviceToHost));
+  PH_HIP(hipMemcpy(old_nb.data(), L.neighbors, old_nb.size() * 4, hipMemcpyDeviceToHost));
+  if (L.nbr_dist) {
+    old_d.resize((size_t)n_old * W);
+    PH_HIP(hipMemcpy(old_d.data(), L.nbr_dist, old_d.size() * 4, hipMemcpyDeviceToHost));
+  }
+  const uint32_t n_new = n_old + (uint32_t)vecs.size();
+  std::vector<uint32_t> nodes(n_new), old_map(n_old);
+  size_t a = 0, b = 0, o = 0;
+  while (a < n_old || b < vecs.size()) {
+    if (b >= vecs.size() || (a < n_old && old_nodes[a] < vecs[b])) {
+      old_map[a] = (uint32_t)o;
+      nodes[o++] = old_nodes[a++];
+    } else {
+      if (a < n_old && old_nodes[a] == vecs[b]) {
+        ph_set_error("extend_layer: tried to insert vector that already exists in this layer");  // lib.rs:1797
+        return PHNSW_E_INVALID;
+      }
+      nodes[o++] = vecs[b++];
+    }
+  }
+  std::vector<uint32_t> nb((size_t)n_new * W, PH_EMPTY32);
+  std::vector<float> nd((size_t)n_new * W, PH_FMAX);
+  for (uint32_t i = 0; i < n_old; i++)
+    for (uint32_t k = 0; k < W; k++) {
+      uint32_t x = old_nb[(size_t)i * W + k];
+      nb[(size_t)old_map[i] * W + k] = x == PH_EMPTY32 ? PH_EMPTY32 : old_map[x];
+      if (!old_d.empty()) nd[(size_t)old_map[i] * W + k] = old_d[(size_t)i * W + k];
+    }
+  PhLayerHost NL;
+  PH_TRY(ph_layer_upload(ix, nodes.data(), nb.data(), n_new, W, &NL));
+  if (!old_d.empty()) {
+    hipError_t e = hipMalloc(&NL.nbr_dist, nd.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(NL.nbr_dist, nd.data(), nd.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      ph_layer_free(NL);
+      return ph_hip_fail(e, "extend_layer upload", __FILE__, __LINE__);
+    }
+  }
+  ph_layer_free(L);
+  ix->layers[lft] = NL;
+  return 0;
+}
+
+// filter_promotion_candidates  lib.rs:1176-1271.  Every unreachable vector of layer `lft`
+// is absent from the layer above, so (nesting invariant) its discover_order_from_top is
+// `lft`: one histogram.  Ties of the count sort (HashMap order in the reference) are
+// broken by node id.
+static int filter_promotion_candidates_impl(phnsw_index *ix, uint32_t lft, const std::vector<uint32_t> &vecs,
+                                            const phnsw_search_params *sp, std::vector<uint32_t> &sel) {
+  sel.clear();
+  if (lft == 0) return 0;
+  const phnsw_store *s = ix->store;
+  PhLayerHost &L = ix->layers[lft];
+  const uint32_t n = L.n_nodes, W = L.W;
+  std::vector<uint32_t> nodes(n), nb((size_t)n * W);
+  PH_HIP(hipMemcpy(nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PH_HIP(hipMemcpy(nb.data(), L.neighbors, nb.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> count(n, 0);
+  for (uint32_t v : vecs) {  // histogramming  :1190-1223
+    uint32_t node = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), v) - nodes.begin());
+    for (uint32_t k = 0; k < W; k++) {
+      uint32_t x = nb[(size_t)node * W + k];
+      if (x == PH_EMPTY32) break;
+      if (std::binary_search(vecs.begin(), vecs.end(), nodes[x])) count[x]++;
+    }
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> histo;  // (count, node)
+  for (uint32_t i = 0; i < n; i++)
+    if (count[i]) histo.push_back({count[i], i});
+  std::sort(histo.begin(), histo.end());
+  std::vector<float> radius;
+  DevBuf<uint32_t> sel_d, one_id, one_len, one_status;
+  DevBuf<float> dist_d, one_d;
+  const uint32_t ef = (uint32_t)sp->number_of_candidates;
+  PH_TRY(sel_d.alloc(histo.size()));
+  PH_TRY(dist_d.alloc(histo.size()));
+  PH_TRY(one_id.alloc(ef));
+  PH_TRY(one_d.alloc(ef));
+  PH_TRY(one_len.alloc(1));
+  PH_TRY(one_status.alloc(1));
+  DevBuf<uint32_t> qd;
+  PH_TRY(qd.alloc(1));
+  std::vector<float> hd;
+  while (!histo.empty()) {  // while let Some((node, _)) = histogram.pop()  :1243
+    uint32_t vec = nodes[histo.back().second];
+    histo.pop_back();
+    bool covered = false;
+    if (!sel.empty()) {  // compare_vec(Stored(v), Stored(vec)) < radius for any selected v  :1244-1249
+      PH_TRY(ph_distance_batch(s, nullptr, vec, sel_d.p, (uint32_t)sel.size(), dist_d.p, 0));
+      hd.resize(sel.size());
+      PH_HIP(hipMemcpy(hd.data(), dist_d.p, sel.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < sel.size() && !covered; k++) covered = hd[k] < radius[k];
+    }
+    if (covered) continue;
+    // radius = self.search_upto(Stored(vec), sp, layer_from_top)[0].1  :1254-1259
+    PH_HIP(hipMemcpy(qd.p, &vec, 4, hipMemcpyHostToDevice));
+    PH_TRY(ph_search_device(ix, nullptr, 0, qd.p, 1, sp, lft, nullptr, one_id.p, one_d.p, one_len.p, nullptr,
+                            one_status.p, 0, 0, 0));
+    float r0 = 0.f;
+    uint32_t l0 = 0;
+    PH_HIP(hipMemcpy(&l0, one_len.p, 4, hipMemcpyDeviceToHost));
+    if (l0) PH_HIP(hipMemcpy(&r0, one_d.p, 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(sel_d.p + sel.size(), &vec, 4, hipMemcpyHostToDevice));
+    sel.push_back(vec);
+    radius.push_back(r0);
+  }
+  return 0;
+}
+
+// promote_at_layer  lib.rs:1273-1427
+static int promote_at_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_build_params *bp, int *promoted) {
+  *promoted = 0;
+  std::vector<uint32_t> vecs;
+  PH_TRY(discover_unreachable_impl(ix, lft, &bp->optimization.search, vecs));
+  if (vecs.empty()) return 0;
+  const float max_proportion = bp->optimization.promotion_proportion;
+  if (max_proportion < 1.0f) {  // :1288-1294
+    vecs.resize((size_t)((float)vecs.size() * max_proportion));
+    if (vecs.empty()) return 0;
+  }
+  std::vector<uint32_t> sel;
+  PH_TRY(filter_promotion_candidates_impl(ix, lft, vecs, &bp->optimization.search, sel));
+  *promoted = 1;
+  if (lft == 0 || sel.empty()) return 0;  // nothing to extend; the reference still returns true
+  // the else branch of :1332-1420 (layer_from_top = lft >= 1)
+  const uint32_t nsz = lft;
+  std::vector<uint64_t> sizes(nsz);
+  for (uint32_t i = 0; i < nsz; i++) sizes[i] = ix->layers[lft - 1 - i].n_nodes;  // reversed: [0] = just above
+  std::vector<uint64_t> new_sizes = calculate_partitions(sizes[0] + sel.size(), bp->order);
+  std::reverse(new_sizes.begin(), new_sizes.end());  // from the bottom
+  if (new_sizes.size() < nsz) new_sizes.resize(nsz, 0);  // :1345-1349
+  const uint32_t retop_upto = (uint32_t)new_sizes.size() - nsz;
+  std::vector<uint64_t> promo(nsz);
+  for (uint32_t i = 0; i < nsz; i++) promo[i] = new_sizes[i] > sizes[i] ? new_sizes[i] - sizes[i] : 0;
+  uint32_t offset = 0;
+  if (retop_upto != 0) {  // :1361-1397
+    const uint32_t retop_index = nsz - retop_upto;
+    uint64_t into_top = std::min<uint64_t>(promo[retop_index], sel.size());
+    promo.resize(retop_index);
+    const PhLayerHost &T = ix->layers[retop_upto - 1];
+    std::vector<uint32_t> tn(T.n_nodes);
+    PH_HIP(hipMemcpy(tn.data(), T.nodes, (size_t)T.n_nodes * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> top(tn.begin(), tn.end());
+    for (uint64_t k = 0; k < into_top; k++) top.push_back(sel[k]);
+    std::sort(top.begin(), top.end());
+    top.erase(std::unique(top.begin(), top.end()), top.end());
+    phnsw_build_params nbp = *bp;
+    nbp.zero_layer_neighborhood_size = bp->neighborhood_size;  // "a fake zero layer"  :1377-1379
+    nbp.seed = bp->seed + 0x51ED270B9F3ULL + ix->layers.size();  // thread_rng in the reference
+    phnsw_index *nt = nullptr;
+    PH_TRY(build_impl(ix->store, top.data(), top.size(), &nbp, nullptr, nullptr, &nt));
+    std::vector<PhLayerHost> nl = nt->layers;
+    nt->layers.clear();
+    const uint32_t new_top_len = (uint32_t)nl.size();
+    for (uint32_t i = 0; i < retop_upto; i++) ph_layer_free(ix->layers[i]);
+    for (size_t i = retop_upto; i < ix->layers.size(); i++) nl.push_back(ix->layers[i]);
+    ix->layers = nl;
+    phnsw_index_destroy(nt);
+    offset = new_top_len;
+  }
+  // promotion_sizes.reverse(); extend each remaining layer above  :1398-1412
+  for (uint32_t i = 0; i < promo.size(); i++) {
+    uint64_t size = promo[promo.size() - 1 - i];
+    uint32_t cur = offset + i;
+    const PhLayerHost &L = ix->layers[cur];
+    std::vector<uint32_t> ln(L.n_nodes), tp;
+    PH_HIP(hipMemcpy(ln.data(), L.nodes, (size_t)L.n_nodes * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < sel.size() && tp.size() < size; k++)
+      if (!std::binary_search(ln.begin(), ln.end(), sel[k])) tp.push_back(sel[k]);
+    PH_TRY(extend_layer_impl(ix, cur, tp));
+  }
+  return 0;
+}
+
+// improve_index_at  lib.rs:1546-1603; *lft_io may grow when promotion adds layers
+static int improve_index_at_impl(phnsw_index *ix, uint32_t *lft_io, const phnsw_build_params *bp, float *out) {
   const phnsw_optimization_params *op = &bp->optimization;
+  uint32_t lft = *lft_io;
   float recall = 0.f;
   PH_TRY(recall_impl(ix, lft, op, &recall));
   float improvement = 1.0f;
@@ -1055,12 +1303,28 @@ static int improve_index_at_impl(phnsw_index *ix, uint32_t lft, const phnsw_buil
     float last = recall;
     uint32_t cur = 0;
     while (cur <= lft && bailout != 0) {
+      size_t layer_count = ix->layers.size();
       PH_TRY(improve_neighbors_upto_impl(ix, cur + 1, bp, NAN, &recall));
+      if (recall == 1.0f) {  // :1569-1572
+        cur++;
+        continue;
+      }
+      if (bp->promote) {
+        int promoted = 0;
+        PH_TRY(promote_at_layer_impl(ix, cur, bp, &promoted));  // :1575
+        if (promoted) {
+          uint32_t delta = (uint32_t)(ix->layers.size() - layer_count);
+          cur += delta;
+          lft += delta;
+          PH_TRY(improve_neighbors_upto_impl(ix, cur + 1, bp, recall, &recall));  // :1586-1587
+        }
+      }
       cur++;
     }
     bailout--;
     improvement = recall - last;
   }
+  *lft_io = lft;
   *out = recall;
   return 0;
 }
@@ -1073,9 +1337,11 @@ static int improve_index_impl(phnsw_index *ix, const phnsw_build_params *bp, phn
   }
   float recall = 0.f;
   PH_TRY(recall_impl(ix, (uint32_t)ix->layers.size() - 1, &bp->optimization, &recall));
-  for (uint32_t lft = 0; lft < ix->layers.size(); lft++) {
-    PH_TRY(improve_index_at_impl(ix, lft, bp, &recall));
-    if (cb && cb(user, "improve_index", lft + 1, ix->layers.size())) {
+  uint32_t lft = 0;
+  while (lft < ix->layers.size()) {  // lib.rs:1673-1683
+    PH_TRY(improve_index_at_impl(ix, &lft, bp, &recall));
+    lft++;
+    if (cb && cb(user, "improve_index", lft, ix->layers.size())) {
       ph_set_error("interrupted by the progress callback");
       return PHNSW_E_INVALID;
     }
@@ -1202,8 +1468,8 @@ extern "C" int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_bu
 }
 
 // Hnsw::generate  lib.rs:825-893
-extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
-                           phnsw_progress_cb cb, void *user, phnsw_index **out) {
+static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                      phnsw_progress_cb cb, void *user, phnsw_index **out) {
   if (!s || !vids || !bp || !out || n == 0 || bp->order < 2) {
     ph_set_error("phnsw_build: invalid argument (need n > 0, order >= 2)");  // assert!(total_size > 0) lib.rs:837
     return PHNSW_E_INVALID;
@@ -1216,11 +1482,13 @@ extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, con
   std::vector<uint64_t> vs(vids, vids + n);
   ph_shuffle_u64(vs.data(), n, bp->seed);  // vs.shuffle(&mut thread_rng())  lib.rs:832-833
   std::vector<uint64_t> parts = calculate_partitions(n, bp->order);
-  for (size_t i = 0; i < parts.size(); i++) {
+  size_t i = 0;
+  while (i != parts.size()) {  // lib.rs:854-890
     uint64_t length = std::min<uint64_t>(parts[i], n);  // lib.rs:858-860
     size_t level = parts.size() - i - 1;
     uint64_t W = level == 0 ? bp->zero_layer_neighborhood_size : bp->neighborhood_size;
     int rc = generate_layer_impl(ix, vs.data(), length, W, bp);
+    size_t old_count = ix->layers.size();
     if (!rc) rc = improve_index_impl(ix, bp, nullptr, nullptr, nullptr);  // lib.rs:877
     if (!rc && cb && cb(user, "generate", i + 1, parts.size())) {
       ph_set_error("interrupted by the progress callback");
@@ -1230,7 +1498,39 @@ extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, con
       phnsw_index_destroy(ix);
       return rc;
     }
+    size_t delta = ix->layers.size() - old_count;
+    if (delta > 0) {  // promotion added layers: fix the partitions  lib.rs:880-887
+      std::vector<uint64_t> np;
+      for (auto &l : ix->layers) np.push_back(l.n_nodes);
+      np.insert(np.end(), parts.begin() + i + 1, parts.end());
+      parts = np;
+      i += delta;
+    }
+    i++;
   }
   *out = ix;
+  return 0;
+}
+
+extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                           phnsw_progress_cb cb, void *user, phnsw_index **out) {
+  return build_impl(s, vids, n, bp, cb, user, out);
+}
+
+extern "C" int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,
+                                      int *out_promoted) {
+  PH_TRY(enter(ix));
+  if (!bp || !out_promoted) return PHNSW_E_INVALID;
+  return promote_at_layer_impl(ix, layer_from_top, bp, out_promoted);
+}
+
+extern "C" int phnsw_discover_unreachable(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                                          uint64_t *out_vecs, uint64_t *out_count) {
+  PH_TRY(enter(ix));
+  if (!sp || !out_vecs || !out_count) return PHNSW_E_INVALID;
+  std::vector<uint32_t> v;
+  PH_TRY(discover_unreachable_impl(ix, layer_from_top, sp, v));
+  for (size_t i = 0; i < v.size(); i++) out_vecs[i] = v[i];
+  *out_count = v.size();
   return 0;
 }

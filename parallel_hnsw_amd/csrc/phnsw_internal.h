@@ -118,6 +118,7 @@ struct PhSearchArgs {
   float threshold;
   uint32_t first_node;  // knn modes: queries are nodes first_node .. first_node + nq
   uint32_t cap_max;     // threshold_nn: largest queue capacity the launch must support (0 = ef)
+  float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
 };
@@ -130,7 +131,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride = 0,
-                     uint32_t *out_hit = nullptr, float threshold = 0.f, uint32_t first_node = 0);
+                     uint32_t *out_hit = nullptr, float threshold = 0.f, uint32_t first_node = 0,
+                     float hit_eps = 0.f);
 
 // launchers (search.hip)
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream);

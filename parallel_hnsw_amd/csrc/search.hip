@@ -448,11 +448,23 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     }
     if (a.out_hit) {
       // res.iter().any(|v| v == *vid)  lib.rs:1492
+      // hit_eps > 0: match_within_epsilon (search.rs:173-187): only the leading results with
+      // |d| < eps count
+      uint32_t cut = clen;
+      if (a.hit_eps > 0.f) {
+#pragma unroll
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          bool far = i < clen && !(fabsf(Cd[i]) < a.hit_eps);
+          uint64_t fmk = __ballot(far);
+          if (fmk && cut == clen) cut = 64u * c + __builtin_ctzll(fmk);
+        }
+      }
       bool hit = false;
 #pragma unroll
       for (int c = 0; c < CAPC; c++) {
         uint32_t i = lane + 64u * c;
-        hit |= (i < clen && Cid[i] == qvec);
+        hit |= (i < cut && Cid[i] == qvec);
       }
       uint64_t hm = __ballot(hit);
       if (lane == 0) a.out_hit[q] = hm ? 1u : 0u;

@@ -256,6 +256,20 @@ class Hnsw:
                                                  C.byref(out)))
         return out.value
 
+    def promote_at_layer(self, layer_from_top, bp=None):
+        """lib.rs:1273-1427"""
+        out = C.c_int()
+        check(lib().phnsw_promote_at_layer(self._h, layer_from_top, C.byref(bp or self.build_parameters), C.byref(out)))
+        return bool(out.value)
+
+    def discover_unreachable_vectors(self, layer_from_top, sp):
+        """lib.rs:1002-1037"""
+        n = self._layer(layer_from_top).node_count()
+        out = np.empty(n, dtype=np.uint64)
+        cnt = C.c_uint64()
+        check(lib().phnsw_discover_unreachable(self._h, layer_from_top, C.byref(sp), _p(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
     def stochastic_recall_at(self, at, op=None):
         out = C.c_float()
         op = op or self.build_parameters.optimization

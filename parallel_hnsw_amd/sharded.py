@@ -141,6 +141,9 @@ class GpuEngine:
         check(lib().phnsw_recall_hits(self.hnsw._h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel)))
         return hits.value, sel.value
 
+    def promote_at_layer(self, lft):
+        return self.hnsw.promote_at_layer(lft, self.bp)
+
 
 class ShardedBuilder:
     """Hnsw::generate with every per-node phase split over the ranks of `comm`"""
@@ -211,7 +214,8 @@ class ShardedBuilder:
                 break
         return float(last)
 
-    # improve_index_at  lib.rs:1546-1603 (promotion not performed)
+    # improve_index_at  lib.rs:1546-1603.  promote_at_layer runs replicated on every rank (its
+    # searches are a small share of a build and the replicas must stay identical).
     def improve_index_at(self, lft):
         op = self.bp.optimization
         recall = np.float32(self.stochastic_recall_at(lft))
@@ -219,27 +223,45 @@ class ShardedBuilder:
         while improvement >= np.float32(op.promotion_threshold) and recall < np.float32(1.0) and bailout != 0:
             last, cur = recall, 0
             while cur <= lft and bailout != 0:
+                layer_count = self.e.layer_count()
                 recall = np.float32(self.improve_neighbors_upto(cur + 1))
+                if recall == np.float32(1.0):
+                    cur += 1
+                    continue
+                if self.bp.promote and self.e.promote_at_layer(cur):
+                    delta = self.e.layer_count() - layer_count
+                    cur += delta
+                    lft += delta
+                    recall = np.float32(self.improve_neighbors_upto(cur + 1, float(recall)))
                 cur += 1
             bailout -= 1
             improvement = recall - last
-        return float(recall)
+        return float(recall), lft
 
     # improve_index  lib.rs:1664-1686
     def improve_index(self):
         recall = self.stochastic_recall_at(self.e.layer_count() - 1)
-        for lft in range(self.e.layer_count()):
-            recall = self.improve_index_at(lft)
+        lft = 0
+        while lft < self.e.layer_count():
+            recall, lft = self.improve_index_at(lft)
+            lft += 1
         return recall
 
     # Hnsw::generate  lib.rs:825-893
     def generate(self, vids):
         vs, sizes = self.e.plan(vids)
         n = len(vs)
-        for i, size in enumerate(sizes):
-            length = min(size, n)
+        i = 0
+        while i != len(sizes):
+            length = min(sizes[i], n)
             level = len(sizes) - i - 1
             W = self.bp.zero_layer_neighborhood_size if level == 0 else self.bp.neighborhood_size
             self.generate_layer(vs[:length], W)
+            old = self.e.layer_count()
             self.improve_index()
+            delta = self.e.layer_count() - old
+            if delta > 0:  # promotion added layers: fix the partitions  lib.rs:880-887
+                sizes = [self.e.layer_nodes(l) for l in range(self.e.layer_count())] + sizes[i + 1:]
+                i += delta
+            i += 1
         return getattr(self.e, "hnsw", None)

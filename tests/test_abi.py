@@ -48,7 +48,7 @@ def test_parameter_defaults_match_reference():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(ph.SearchParams) == 24
     assert C.sizeof(ph.OptimizationParams) == 40
-    assert C.sizeof(ph.BuildParams) == 24 + 40 + 24 + 16
+    assert C.sizeof(ph.BuildParams) == 24 + 40 + 24 + 24
 
 
 def _no_gpu():

@@ -266,3 +266,47 @@ def test_two_ranks_one_gpu_rehearsal(tmp_path):
         assert int(z["gathered"]) > 0
         for l in range(ref.layer_count()):
             np.testing.assert_array_equal(z["nb%d" % l], ref._layer(l).neighbors, err_msg="rank %d layer %d" % (r, l))
+
+
+def _dup_rows(points=40, copies=60, dim=16):
+    base = oracle.synth_rows(0, points, dim)
+    return np.repeat(base, copies, axis=0).copy()
+
+
+def _weak_bp(mod, promote=1):
+    bp = mod(promote=promote, seed=1, order=6, neighborhood_size=4, zero_layer_neighborhood_size=8)
+    bp.optimization.recall_proportion = 1.0
+    s = bp.optimization.search
+    s.number_of_candidates, s.upper_layer_candidate_count = 16, 16
+    return bp
+
+
+def test_promotion_parity():
+    """promote_at_layer / extend_layer / re-topping (lib.rs:1002-1068, 1167-1427) driven by GPU
+    searches: same layers as the oracle on data whose duplicates leave nodes unreachable"""
+    rows = _dup_rows()
+    n = rows.shape[0]
+    oix = oracle.Index.generate(rows, np.arange(n), _weak_bp(obp), dim=16, sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :16])
+    gix = ph.Hnsw.generate(store, np.arange(n), _weak_bp(gbp))
+    sizes = [gix._layer(l).node_count() for l in range(gix.layer_count())]
+    assert sum(sizes[:-1]) > sum(oracle.calculate_partitions(n, 6)[:-1])  # promotion really happened
+    layers_equal(gix, oix)
+    assert oix.check_layer_invariants() == 0
+    # the pieces one by one on a fresh (unpromoted) stack
+    o0 = oracle.Index.generate(rows, np.arange(n), _weak_bp(obp, 0), dim=16, sum_mode=oracle.SUM_BLOCKED64)
+    g0 = ph.Hnsw.generate(store, np.arange(n), _weak_bp(gbp, 0))
+    layers_equal(g0, o0)
+    sp = (16, 16, 2)
+    for lft in range(o0.layer_count):
+        np.testing.assert_array_equal(g0.discover_unreachable_vectors(lft, ph.SearchParameters(*sp)),
+                                      o0.discover_unreachable(lft, sp))
+    lft = o0.layer_count - 1
+    assert g0.promote_at_layer(lft, _weak_bp(gbp)) == (o0.promote_at_layer(lft, _weak_bp(obp)) > 0)
+    layers_equal(g0, o0)
+    # searching the promoted stack still agrees (new upper-layer nodes have empty rows until linked)
+    q = oracle.synth_rows(2 ** 32, 64, 16)[:, :16]
+    gi, gd, gl = g0.search_batch(queries=q, sp=ph.SearchParameters(32, 32, 2))
+    ci, cd, cl = o0.search(queries=q, sp=(32, 32, 2))
+    np.testing.assert_array_equal(gi, ci)
+    np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))

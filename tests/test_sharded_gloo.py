@@ -68,6 +68,9 @@ class OracleEngine:
     def link_apply(self, lft, M, ids, d, ln):
         return int(self.L.orc_link_apply(self.ix.h, lft, M, self._p(ids), self._p(d), self._p(ln), self.threads))
 
+    def promote_at_layer(self, lft):
+        return self.ix.promote_at_layer(lft, self.bp, threads=self.threads) > 0
+
     def recall_hits(self, at, op, first, count):
         hits, sel = C.c_uint64(), C.c_uint64()
         assert self.L.orc_recall_hits(self.ix.h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel),
@@ -78,7 +81,30 @@ class OracleEngine:
 CASES = [
     dict(n=700, dim=16, kw=dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12, seed=3)),
     dict(n=1501, dim=24, kw=dict(seed=1)),   # odd size: ranges of unequal length
+    # duplicate-heavy data: rows cannot hold every copy, nodes stay unreachable, promotion
+    # (lib.rs:1273-1427) extends and re-tops the upper layers while the build is sharded
+    dict(n=1200, dim=16, dup=40, kw=dict(order=6, neighborhood_size=4, zero_layer_neighborhood_size=8, seed=1),
+         search=(16, 16, 2), recall_proportion=1.0),
 ]
+
+
+def _case_rows(case):
+    import oracle
+    if case.get("dup"):
+        base = oracle.synth_rows(0, case["n"] // case["dup"], case["dim"])
+        return np.repeat(base, case["dup"], axis=0).copy()
+    return oracle.synth_rows(0, case["n"], case["dim"])
+
+
+def _case_bp(case):
+    import oracle
+    bp = oracle.default_build_params(**case["kw"])
+    if "search" in case:
+        s = bp.optimization.search
+        s.number_of_candidates, s.upper_layer_candidate_count, s.probe_depth = case["search"]
+    if "recall_proportion" in case:
+        bp.optimization.recall_proportion = case["recall_proportion"]
+    return bp
 
 
 def _worker(rank, world, port, case, out_dir):
@@ -89,8 +115,8 @@ def _worker(rank, world, port, case, out_dir):
     from parallel_hnsw_amd.sharded import ShardedBuilder, TorchComm
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows = oracle.synth_rows(0, case["n"], case["dim"])
-        bp = oracle.default_build_params(**case["kw"])
+        rows = _case_rows(case)
+        bp = _case_bp(case)
         eng = OracleEngine(rows, case["dim"], bp)
         comm = TorchComm()
         b = ShardedBuilder(eng, comm)
@@ -112,9 +138,12 @@ def test_sharded_build_equals_single_process(case, tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
-    rows = oracle.synth_rows(0, case["n"], case["dim"])
-    ref = oracle.Index.generate(rows, np.arange(case["n"]), oracle.default_build_params(**case["kw"]),
+    rows = _case_rows(case)
+    ref = oracle.Index.generate(rows, np.arange(case["n"]), _case_bp(case),
                                 dim=case["dim"], sum_mode=oracle.SUM_BLOCKED64, threads=4)
+    if case.get("dup"):
+        assert ref.layer_count > len(oracle.calculate_partitions(case["n"], case["kw"]["order"])) or \
+            ref.layer(ref.layer_count - 2)[0].shape[0] > case["n"] // case["kw"]["order"]  # promotion happened
     for rank in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert int(z["count"]) == ref.layer_count
