@@ -236,6 +236,9 @@ int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_opti
  * ksub <= 256, m*ksub*4 bytes must fit the LDS. */
 int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out);
 int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);
+/* keep the per-query lookup table as IEEE half values (half the LDS, more resident waves);
+ * set it before building an index over the store */
+int phnsw_pq_set_table_f16(phnsw_store *s, int on);
 int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook);
 /* QuantizedHnsw::search  pq.rs:346-364 for a batch: search the index over the PQ store, re-rank
  * every result with the full-precision store, sort by (distance, id).  quantize_query != 0

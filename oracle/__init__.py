@@ -49,7 +49,8 @@ class BuildParams(C.Structure):
 class Store(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("n", C.c_uint64), ("dim", C.c_uint32), ("ld", C.c_uint32),
                 ("metric", C.c_int), ("sum_mode", C.c_int), ("codes", C.c_void_p), ("codebook", C.c_void_p),
-                ("pq_m", C.c_uint32), ("pq_ksub", C.c_uint32), ("pq_dsub", C.c_uint32)]
+                ("pq_m", C.c_uint32), ("pq_ksub", C.c_uint32), ("pq_dsub", C.c_uint32),
+                ("pq_table_f16", C.c_uint32)]
 
 
 class LayerS(C.Structure):
@@ -150,6 +151,7 @@ def lib():
         L.orc_pq_create.restype = i32
         L.orc_pq_create.argtypes = [vp, u64, u32, u32, u32, u32, u64, vp, vp, i32]
         L.orc_index_set_pq.argtypes = [vp, vp, vp, u32, u32, u32]
+        L.orc_index_set_pq_table_f16.argtypes = [vp, i32]
         L.orc_pq_search_batch.restype = i32
         L.orc_pq_search_batch.argtypes = [vp, C.POINTER(Store), vp, u32, u64, SearchParams, i32, vp, vp, vp, vp, i32]
         L.orc_feistel_perm.restype = u64
@@ -285,7 +287,7 @@ class Index:
 
     def store(self, sum_mode=None):
         return Store(_p(self.rows), self.rows.shape[0], self.dim, self.ld, self.metric,
-                     self._sum_mode if sum_mode is None else sum_mode, None, None, 0, 0, 0)
+                     self._sum_mode if sum_mode is None else sum_mode, None, None, 0, 0, 0, 0)
 
     _sum_mode = SUM_SEQ
 
@@ -407,13 +409,14 @@ class Index:
         return lib().orc_improve_index(self.h, C.byref(bp), threads)
 
     # -- product quantisation (pq.rs) --
-    def set_pq(self, codes, codebook):
+    def set_pq(self, codes, codebook, table_f16=False):
         """turn this index's store into a PQ store over the given codes / codebooks"""
         self.pq_codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.pq_codebook = np.ascontiguousarray(codebook, dtype=np.float32)
         m, ksub, dsub = self.pq_codebook.shape
         assert self.pq_codes.shape == (self.rows.shape[0], m)
         lib().orc_index_set_pq(self.h, _p(self.pq_codes), _p(self.pq_codebook), m, ksub, dsub)
+        lib().orc_index_set_pq_table_f16(self.h, int(table_f16))
 
     def pq_search(self, full, queries, sp, quantize_query=False, threads=8, stats=False):
         """QuantizedHnsw::search: `full` is an Index over the f32 rows (its sum mode is used)"""

@@ -55,6 +55,7 @@ typedef struct {
   const uint8_t *codes;
   const float *codebook;
   uint32_t pq_m, pq_ksub, pq_dsub;
+  uint32_t pq_table_f16; /* table entries rounded to IEEE half once */
 } orc_store;
 
 float orc_distance(const orc_store *s, const float *a, const float *b);
@@ -218,6 +219,7 @@ void orc_pq_encode(const float *rows, uint64_t n, uint32_t ld, uint32_t m, uint3
 /* turn the index's store into a PQ store (the arrays must outlive the index) */
 void orc_index_set_pq(orc_index *ix, const uint8_t *codes, const float *codebook, uint32_t m, uint32_t ksub,
                       uint32_t dsub);
+void orc_index_set_pq_table_f16(orc_index *ix, int on);
 /* QuantizedHnsw::search pq.rs:346-364: search the code graph, re-rank with the full store
  * (sum_mode of `full`), sort (d, id) */
 int orc_pq_search_batch(const orc_index *ix, const orc_store *full, const float *queries, uint32_t ldq,

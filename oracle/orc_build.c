@@ -931,7 +931,10 @@ static orc_index *generate_impl(const float *rows, uint64_t n_store, uint32_t di
   orc_index *ix = orc_index_new(rows, n_store, dim, ld, metric, sum_mode);
   if (!ix) return NULL;
   if (pq_from && pq_from->codes)
+  {
     orc_index_set_pq(ix, pq_from->codes, pq_from->codebook, pq_from->pq_m, pq_from->pq_ksub, pq_from->pq_dsub);
+    orc_index_set_pq_table_f16(ix, (int)pq_from->pq_table_f16);
+  }
   uint64_t *vs = (uint64_t *)malloc(sizeof(uint64_t) * n);
   memcpy(vs, vids, sizeof(uint64_t) * n);
   orc_shuffle_u64(vs, n, bp->seed); /* vs.shuffle(&mut thread_rng()) :832-833 */

@@ -18,6 +18,55 @@
 
 #include "orc_internal.h"
 
+/* f32 -> IEEE binary16 -> f32 with round to nearest even (integer arithmetic, the same
+ * steps as the device code) */
+static float round_to_f16(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  uint32_t x = v.u, sign = (x >> 16) & 0x8000u, mant = x & 0x007FFFFFu, hbits;
+  int32_t exp = (int32_t)((x >> 23) & 0xFF);
+  if (exp == 0xFF)
+    hbits = sign | 0x7C00u | (mant ? 0x200u : 0);
+  else {
+    int32_t e = exp - 127 + 15;
+    if (e >= 0x1F)
+      hbits = sign | 0x7C00u;
+    else if (e <= 0) {
+      if (e < -10)
+        hbits = sign;
+      else {
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - e), hm = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        hbits = sign | hm;
+      }
+    } else {
+      uint32_t hm = mant >> 13, rem = mant & 0x1FFFu;
+      hbits = sign | ((uint32_t)e << 10) | hm;
+      if (rem > 0x1000u || (rem == 0x1000u && (hm & 1u))) hbits++;
+    }
+  }
+  uint32_t s2 = (hbits & 0x8000u) << 16, e2 = (hbits >> 10) & 0x1Fu, m2 = hbits & 0x3FFu, u;
+  if (e2 == 0) {
+    if (m2 == 0)
+      u = s2;
+    else {
+      int s = 0;
+      while (!(m2 & 0x400u)) {
+        m2 <<= 1;
+        s++;
+      }
+      u = s2 | ((uint32_t)(127 - 15 - s + 1) << 23) | ((m2 & 0x3FFu) << 13);
+    }
+  } else if (e2 == 0x1F)
+    u = s2 | 0x7F800000u | (m2 << 13);
+  else
+    u = s2 | ((e2 - 15 + 127) << 23) | (m2 << 13);
+  v.u = u;
+  return v.f;
+}
+
 static void pq_build_table(const orc_store *S, const float *raw, const uint8_t *qcodes, float *T) {
   const int l2 = S->metric == ORC_METRIC_L2;
   for (uint32_t j = 0; j < S->pq_m; j++) {
@@ -34,7 +83,7 @@ static void pq_build_table(const orc_store *S, const float *raw, const uint8_t *
           acc = fmaf(qs[e], c[e], acc);
         }
       }
-      T[j * S->pq_ksub + k] = acc;
+      T[j * S->pq_ksub + k] = S->pq_table_f16 ? round_to_f16(acc) : acc;
     }
   }
 }
@@ -67,6 +116,8 @@ float orc_query_dist(const orc_store *S, const orc_scratch *sc, uint64_t vid) {
   for (uint32_t j = 0; j < S->pq_m; j++) r = r + sc->pq_table[j * S->pq_ksub + code[j]];
   return metric_epilogue(S, r);
 }
+
+void orc_index_set_pq_table_f16(orc_index *ix, int on) { ix->store.pq_table_f16 = on ? 1u : 0u; }
 
 void orc_index_set_pq(orc_index *ix, const uint8_t *codes, const float *codebook, uint32_t m, uint32_t ksub,
                       uint32_t dsub) {

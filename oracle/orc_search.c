@@ -21,6 +21,7 @@ orc_index *orc_index_new(const float *rows, uint64_t n, uint32_t dim, uint32_t l
   ix->store.sum_mode = sum_mode;
   ix->store.codes = NULL;
   ix->store.codebook = NULL;
+  ix->store.pq_table_f16 = 0;
   return ix;
 }
 

@@ -196,12 +196,67 @@ struct DistF32 {
   }
 };
 
+// f32 -> IEEE binary16 bits, round to nearest even, written with integer operations so that
+// the oracle's C version produces the same bits (no dependence on a denormal mode)
+__host__ __device__ inline uint16_t ph_f32_to_f16_bits(float f) {
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.f = f;
+  uint32_t x = v.u;
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t mant = x & 0x007FFFFFu;
+  int32_t exp = (int32_t)((x >> 23) & 0xFF);
+  if (exp == 0xFF) return (uint16_t)(sign | 0x7C00u | (mant ? 0x200u : 0));
+  int32_t e = exp - 127 + 15;
+  if (e >= 0x1F) return (uint16_t)(sign | 0x7C00u);
+  if (e <= 0) {
+    if (e < -10) return (uint16_t)sign;
+    mant |= 0x00800000u;
+    uint32_t shift = (uint32_t)(14 - e);
+    uint32_t hm = mant >> shift;
+    uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1u))) hm++;
+    return (uint16_t)(sign | hm);
+  }
+  uint32_t hm = mant >> 13, rem = mant & 0x1FFFu;
+  uint32_t out = sign | ((uint32_t)e << 10) | hm;
+  if (rem > 0x1000u || (rem == 0x1000u && (hm & 1u))) out++;  // may carry into the exponent: correct
+  return (uint16_t)out;
+}
+__host__ __device__ inline float ph_f16_bits_to_f32(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu, u;
+  if (e == 0) {
+    if (m == 0)
+      u = sign;
+    else {
+      int s = 0;
+      while (!(m & 0x400u)) {
+        m <<= 1;
+        s++;
+      }
+      u = sign | ((uint32_t)(127 - 15 - s + 1) << 23) | ((m & 0x3FFu) << 13);
+    }
+  } else if (e == 0x1F)
+    u = sign | 0x7F800000u | (m << 13);
+  else
+    u = sign | ((e - 15 + 127) << 23) | (m << 13);
+  union {
+    uint32_t u;
+    float f;
+  } v;
+  v.u = u;
+  return v.f;
+}
+
 struct DistPQ {
-  float *T;  // LDS [m][ksub]
+  float *T;  // LDS [m][ksub] (f32) or the same region viewed as uint16_t [m][ksub]
   // q_sub_j comes from `q` (raw query, dim floats) or from the codebook entry of a stored code
   __device__ __forceinline__ void build(const PhDistArgs &d, const float *q, const uint8_t *qcodes, float *lds,
                                         uint32_t lane) {
     T = lds;
+    uint16_t *T16 = (uint16_t *)lds;
     const bool l2 = d.metric == PHNSW_METRIC_L2;
     for (uint32_t j = 0; j < d.m; j++) {
       const float *qs = q ? q + (uint64_t)j * d.dsub
@@ -217,7 +272,10 @@ struct DistPQ {
             acc = fmaf(qs[e], c[e], acc);
           }
         }
-        T[j * d.ksub + k] = acc;
+        if (d.table_f16)
+          T16[j * d.ksub + k] = ph_f32_to_f16_bits(acc);
+        else
+          T[j * d.ksub + k] = acc;
       }
     }
     __syncthreads();
@@ -228,6 +286,9 @@ struct DistPQ {
   __device__ __forceinline__ void prepare_stored(const PhDistArgs &d, uint32_t vid, float *lds, uint32_t lane) {
     build(d, nullptr, d.codes + (uint64_t)vid * d.m, lds, lane);
   }
+  __device__ __forceinline__ float at(const PhDistArgs &d, uint32_t idx) const {
+    return d.table_f16 ? ph_f16_bits_to_f32(((const uint16_t *)T)[idx]) : T[idx];
+  }
   __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
     float r = 0.f;
     if ((mask >> lane) & 1ull) {
@@ -235,10 +296,10 @@ struct DistPQ {
       for (uint32_t w = 0; w < d.m / 4; w++) {
         uint32_t cw = row[w];
         uint32_t j = 4 * w;
-        r = __fadd_rn(r, T[(j + 0) * d.ksub + (cw & 0xFF)]);
-        r = __fadd_rn(r, T[(j + 1) * d.ksub + ((cw >> 8) & 0xFF)]);
-        r = __fadd_rn(r, T[(j + 2) * d.ksub + ((cw >> 16) & 0xFF)]);
-        r = __fadd_rn(r, T[(j + 3) * d.ksub + (cw >> 24)]);
+        r = __fadd_rn(r, at(d, (j + 0) * d.ksub + (cw & 0xFF)));
+        r = __fadd_rn(r, at(d, (j + 1) * d.ksub + ((cw >> 8) & 0xFF)));
+        r = __fadd_rn(r, at(d, (j + 2) * d.ksub + ((cw >> 16) & 0xFF)));
+        r = __fadd_rn(r, at(d, (j + 3) * d.ksub + (cw >> 24)));
       }
       r = finalize_metric(r, d.metric);
     }

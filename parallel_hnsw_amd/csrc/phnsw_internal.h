@@ -51,6 +51,7 @@ struct PhDistArgs {
   const uint8_t *codes;   // [n][m] u8 codes (PQ store)
   const float *codebook;  // [m][ksub][dsub]
   uint32_t m, ksub, dsub;
+  uint32_t table_f16;  // 1: the per-query table holds IEEE half values (2 bytes per entry)
 };
 
 struct phnsw_store {
@@ -61,6 +62,7 @@ struct phnsw_store {
   uint8_t *codes = nullptr;
   float *codebook = nullptr;
   uint32_t pq_m = 0, pq_ksub = 0, pq_dsub = 0;
+  uint32_t pq_table_f16 = 0;
   bool owns_rows = true;
   uint64_t n = 0;
   uint32_t dim = 0, ld = 0;
@@ -150,9 +152,12 @@ static inline PhDistArgs ph_dist_args(const phnsw_store *s) {
   d.m = s->pq_m;
   d.ksub = s->pq_ksub;
   d.dsub = s->pq_dsub;
+  d.table_f16 = s->pq_table_f16;
   return d;
 }
-static inline size_t ph_pq_lds_bytes(const phnsw_store *s) { return s->codes ? (size_t)s->pq_m * s->pq_ksub * 4 : 0; }
+static inline size_t ph_pq_lds_bytes(const phnsw_store *s) {
+  return s->codes ? (size_t)s->pq_m * s->pq_ksub * (s->pq_table_f16 ? 2 : 4) : 0;
+}
 
 // misc kernels (misc.hip)
 int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,

@@ -188,6 +188,18 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   return 0;
 }
 
+// store the per-query lookup table as IEEE half values (48 KiB instead of 96 KiB at m=96,
+// ksub=256: three resident waves per CU instead of one).  Changes the quantised distances
+// (each table entry is rounded once); graphs must be built with the same setting.
+extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) {
+  if (!s || !s->codes) {
+    ph_set_error("not a product-quantised store");
+    return PHNSW_E_INVALID;
+  }
+  s->pq_table_f16 = on ? 1u : 0u;
+  return 0;
+}
+
 extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) {
   if (!s || !s->codes) {
     ph_set_error("not a product-quantised store");

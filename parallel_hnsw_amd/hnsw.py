@@ -124,10 +124,13 @@ class VectorStore:
 class PqStore(VectorStore):
     """product-quantised view of a VectorStore (pq.rs): u8 codes over per-sub-space codebooks"""
 
-    def __init__(self, full, m, ksub=256, seed=0):
+    def __init__(self, full, m, ksub=256, seed=0, table_f16=False):
         h = C.c_void_p()
         check(lib().phnsw_store_create_pq(full._h, m, ksub, seed, C.byref(h)))
         VectorStore.__init__(self, _handle=h, device=full.device)
+        if table_f16:
+            check(lib().phnsw_pq_set_table_f16(self._h, 1))
+        self.table_f16 = bool(table_f16)
         self.full = full
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().phnsw_pq_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
@@ -147,12 +150,12 @@ class PqStore(VectorStore):
 class QuantizedHnsw:
     """QuantizedHnsw (pq.rs:120-131, 287-364): quantizer + Hnsw over the codes + full comparator"""
 
-    def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None):
+    def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False):
         """QuantizedHnsw::new(number_of_centroids, comparator, bp): per-sub-space codebooks of
         `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes"""
         m = m or max(4, comparator.dim // 8)
         self.full = comparator
-        self.store = PqStore(comparator, m, number_of_centroids, seed)
+        self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16)
         vids = np.arange(comparator.n, dtype=np.uint64) if vids is None else vids
         self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters())
 
