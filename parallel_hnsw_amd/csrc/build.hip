@@ -442,6 +442,12 @@ __global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const 
 
 static int nv_for(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
 static bool store_supported(const phnsw_store *s) { return s->codes ? true : nv_for(s->ld / 4) != 0; }
+// resident one-wave blocks a PQ kernel can have per chip: the lookup table dominates the LDS
+static uint32_t pq_grid(const phnsw_store *s, uint32_t want) {
+  size_t per = ph_pq_lds_bytes(s) + 8 * 1024;
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, (160 * 1024) / per);
+  return std::min<uint32_t>(want, 256u * std::min<uint32_t>(per_cu, 16u));
+}
 
 template <typename K1, typename K3, typename K6, typename KQ, typename... Args>
 static int launch_by_policy(const phnsw_store *s, dim3 g, K1 k1, K3 k3, K6 k6, KQ kq, Args... args) {
@@ -514,7 +520,7 @@ static int ensure_row_dist(phnsw_index *ix, PhLayerHost &L) {
   const phnsw_store *s = ix->store;
   PH_HIP(hipMalloc(&L.nbr_dist, (size_t)L.n_nodes * L.W * 4));
   // a PQ table takes most of a CU's LDS: one resident wave per CU is all that fits
-  dim3 g(s->codes ? std::min<uint32_t>(L.n_nodes, 256u) : wave_grid(L.n_nodes));
+  dim3 g(s->codes ? pq_grid(s, L.n_nodes) : wave_grid(L.n_nodes));
   return launch_by_policy(s, g, ph_row_dist_kernel<DistF32<1>>, ph_row_dist_kernel<DistF32<3>>,
                           ph_row_dist_kernel<DistF32<6>>, ph_row_dist_kernel<DistPQ>, ph_dist_args(s), L.nodes, L.n_nodes,
                           L.W, L.neighbors, L.nbr_dist);
@@ -850,7 +856,7 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   a.count = count;
   a.rows = out_rows;
   a.rows_d = out_rows_d;
-  dim3 g(s->codes ? std::min<uint32_t>(count, 256u) : wave_grid(count));
+  dim3 g(s->codes ? pq_grid(s, count) : wave_grid(count));
   PH_TRY(launch_by_policy(s, g, ph_seed_rows_kernel<DistF32<1>>, ph_seed_rows_kernel<DistF32<3>>,
                           ph_seed_rows_kernel<DistF32<6>>, ph_seed_rows_kernel<DistPQ>, a));
   PH_HIP(hipDeviceSynchronize());

@@ -152,12 +152,18 @@ class QuantizedHnsw:
 
     def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False):
         """QuantizedHnsw::new(number_of_centroids, comparator, bp): per-sub-space codebooks of
-        `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes"""
+        `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes.
+
+        Without an explicit `bp` the graph over the codes is built with promote=0: a
+        reconstruction is not unit length, so a stored code's distance to itself is not within
+        the 1e-5 of match_within_epsilon (search.rs:173-187), every vector counts as
+        "unreachable" and promote_at_layer's sequential thinning (lib.rs:1243-1262, quadratic in
+        the candidates) never finishes at scale -- in the reference as much as here."""
         m = m or max(4, comparator.dim // 8)
         self.full = comparator
         self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16)
         vids = np.arange(comparator.n, dtype=np.uint64) if vids is None else vids
-        self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters())
+        self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters(promote=0))
 
     def search_batch(self, queries, sp=None, quantize_query=False, stats=False):
         sp = sp or SearchParameters()

@@ -12,10 +12,10 @@ import parallel_hnsw_amd as ph
 pytestmark = pytest.mark.gpu
 
 
-def make(n, dim, m, ksub, seed=0, metric=0, clustered=False):
+def make(n, dim, m, ksub, seed=0, metric=0, clustered=False, table_f16=False):
     rows = (oracle.synth_clustered_rows(0, n, dim, n_clusters=20) if clustered else oracle.synth_rows(0, n, dim))
     full = ph.VectorStore(rows[:, :dim], metric=metric)
-    pq = ph.PqStore(full, m, ksub, seed)
+    pq = ph.PqStore(full, m, ksub, seed, table_f16=table_f16)
     ocodes, ocb = oracle.pq_create(rows, dim, m, ksub, seed)
     return rows, full, pq, ocodes, ocb
 
@@ -69,13 +69,14 @@ def test_quantised_distance_batch_bit_exact(metric):
     np.testing.assert_array_equal(got_s.view(np.uint32), exp_s.view(np.uint32))
 
 
-@pytest.mark.parametrize("n,dim,m,ksub", [(2500, 64, 16, 256), (1500, 768, 96, 256)])
-def test_pq_index_build_and_search_parity(n, dim, m, ksub):
-    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=1, clustered=True)
-    bp_kw = dict(seed=2)
+@pytest.mark.parametrize("n,dim,m,ksub,f16", [(2500, 64, 16, 256, False), (1500, 768, 96, 256, False),
+                                              (1500, 768, 96, 256, True), (2000, 64, 16, 128, True)])
+def test_pq_index_build_and_search_parity(n, dim, m, ksub, f16):
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=1, clustered=True, table_f16=f16)
+    bp_kw = dict(seed=2, promote=0)
     # oracle: Hnsw::generate over the code rows (QuantizedHnsw::new pq.rs:337-338)
     oix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
-    oix.set_pq(ocodes, ocb)
+    oix.set_pq(ocodes, ocb, table_f16=f16)
     obp = oracle.default_build_params(**bp_kw)
     vs = oracle.shuffle(np.arange(n), obp.seed)
     sizes = oracle.calculate_partitions(n, obp.order)
