@@ -1,5 +1,6 @@
 // Device helpers shared by the gfx950 kernels (wave64 only).
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 #include "phnsw_internal.h"
@@ -287,7 +288,8 @@ struct DistPQ {
     build(d, nullptr, d.codes + (uint64_t)vid * d.m, lds, lane);
   }
   __device__ __forceinline__ float at(const PhDistArgs &d, uint32_t idx) const {
-    return d.table_f16 ? ph_f16_bits_to_f32(((const uint16_t *)T)[idx]) : T[idx];
+    // half -> float is exact; v_cvt_f32_f16 does it in one instruction
+    return d.table_f16 ? __half2float(__ushort_as_half(((const uint16_t *)T)[idx])) : T[idx];
   }
   __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
     float r = 0.f;
