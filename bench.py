@@ -185,6 +185,11 @@ def main():
             e = [s for s in sweep if s["ef"] == 128 and s["probe_depth"] == 2] or sweep[:1]
             chosen = (e[0]["ef"], e[0]["probe_depth"], e[0]["qps_cal"], e[0]["recall_at_10"])
         ef, pd = chosen[0], chosen[1]
+        if world > 1:
+            # the sweep is timing based: all ranks adopt rank 0's choice (outside the timed region)
+            t = torch.tensor([ef, pd, int(met)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            ef, pd, met = int(t[0]), int(t[1]), bool(int(t[2]))
         sp = ph.SearchParameters(ef, ef, pd)
         # this rank's own query batch (weak scaling: fixed work per GPU)
         qstore = make_store(kind, args.nq, 2 ** 32 + rank * args.nq)
