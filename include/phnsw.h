@@ -223,6 +223,13 @@ int phnsw_link_search_device(phnsw_index *ix, uint32_t layer_from_top, const phn
 int phnsw_link_apply_device(phnsw_index *ix, uint32_t layer_from_top, uint64_t link_count,
                             const uint32_t *ids, const float *d, const uint32_t *len,
                             uint64_t *out_added);
+/* promote_at_layer in two phases: the self-hit flags (match_within_epsilon) of nodes
+ * [first, first+count) -> all-gather -> the promotion from the FULL [node_count] flags */
+int phnsw_discover_hits_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                               uint64_t first, uint64_t count, uint32_t *out_hit);
+int phnsw_promote_at_layer_hits_device(phnsw_index *ix, uint32_t layer_from_top,
+                                       const phnsw_build_params *bp, const uint32_t *hit,
+                                       int *out_promoted);
 /* self-hits among sample[first, first+count) of stochastic_recall_at; *out_selection = sample size */
 int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
                       uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection);

@@ -137,6 +137,10 @@ def lib():
         L.orc_improve_index.argtypes = [vp, C.POINTER(BuildParams), i32]
         L.orc_promote_at_layer.restype = i32
         L.orc_promote_at_layer.argtypes = [vp, u32, C.POINTER(BuildParams), i32]
+        L.orc_discover_hits.restype = i32
+        L.orc_discover_hits.argtypes = [vp, u32, SearchParams, u64, u64, vp, i32]
+        L.orc_promote_at_layer_hits.restype = i32
+        L.orc_promote_at_layer_hits.argtypes = [vp, u32, C.POINTER(BuildParams), vp, i32]
         L.orc_extend_layer.restype = i32
         L.orc_extend_layer.argtypes = [vp, u32, vp, u64]
         L.orc_discover_unreachable.restype = u64

@@ -195,6 +195,10 @@ uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t layer_from_top, 
                                   uint64_t **out, int threads);
 /* promote_at_layer lib.rs:1273-1427 (deterministic tie order) ; 1 = promoted */
 int orc_promote_at_layer(orc_index *ix, uint32_t layer_from_top, const orc_build_params *bp, int threads);
+int orc_discover_hits(const orc_index *ix, uint32_t layer_from_top, orc_search_params sp, uint64_t first,
+                      uint64_t count, uint64_t *out_hit, int threads);
+int orc_promote_at_layer_hits(orc_index *ix, uint32_t layer_from_top, const orc_build_params *bp,
+                              const uint64_t *hit, int threads);
 /* extend_layer lib.rs:1039-1068 (layer counted from the top here) */
 int orc_extend_layer(orc_index *ix, uint32_t layer_from_top, const uint64_t *vecs, uint64_t count);
 /* assert_layer_invariants search.rs:142-171 ; 0 = ok */

@@ -631,13 +631,12 @@ static int match_within_epsilon(uint64_t vector, const uint64_t *ids, const floa
   return found;
 }
 
-/* discover_unreachable_vectors  src/lib.rs:1002-1037 */
-uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t **out,
-                                  int threads) {
+/* self-hit flags (match_within_epsilon) of nodes [first, first+count) of layer lft: the
+ * searches of discover_unreachable_vectors  src/lib.rs:1017-1025 */
+int orc_discover_hits(const orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t first, uint64_t count,
+                      uint64_t *out_hit, int threads) {
   const orc_layer *cur = &ix->layers[lft];
-  const orc_layer *above = lft ? &ix->layers[lft - 1] : NULL;
-  uint64_t n = cur->node_count;
-  uint8_t *flag = (uint8_t *)calloc(n, 1);
+  if (first + count > cur->node_count) return -3;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_scratch *sc = orc_scratch_new(ix, 0);
@@ -645,25 +644,39 @@ uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t lft, orc_search_
     uint64_t *oi = (uint64_t *)malloc(sizeof(uint64_t) * cap);
     float *od = (float *)malloc(sizeof(float) * cap);
 #pragma omp for schedule(dynamic, 16)
-    for (uint64_t i = 0; i < n; i++) {
-      uint64_t vector = cur->nodes[i], len = 0;
+    for (uint64_t x = 0; x < count; x++) {
+      uint64_t vector = cur->nodes[first + x], len = 0;
       orc_search_sc(ix, NULL, vector, sp, lft + 1, ORC_EMPTY, oi, od, &len, NULL, sc, NULL);
-      int in_matches = match_within_epsilon(vector, oi, od, len);
-      if (!in_matches && (!above || orc_layer_get_node(above, vector) == ORC_EMPTY)) flag[i] = 1;
+      out_hit[x] = (uint64_t)match_within_epsilon(vector, oi, od, len);
     }
     free(oi);
     free(od);
     orc_scratch_free(sc);
   }
-  uint64_t cnt = 0;
-  for (uint64_t i = 0; i < n; i++) cnt += flag[i];
-  uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t) * (cnt ? cnt : 1));
-  uint64_t c = 0;
+  return 0;
+}
+
+/* the filter of discover_unreachable_vectors  src/lib.rs:1026-1034 from the full flags */
+static uint64_t discover_filter(const orc_index *ix, uint32_t lft, const uint64_t *hit, uint64_t **out) {
+  const orc_layer *cur = &ix->layers[lft];
+  const orc_layer *above = lft ? &ix->layers[lft - 1] : NULL;
+  uint64_t n = cur->node_count, c = 0;
+  uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
   for (uint64_t i = 0; i < n; i++)
-    if (flag[i]) v[c++] = cur->nodes[i];
-  free(flag);
+    if (!hit[i] && (!above || orc_layer_get_node(above, cur->nodes[i]) == ORC_EMPTY)) v[c++] = cur->nodes[i];
   *out = v;
-  return cnt;
+  return c;
+}
+
+/* discover_unreachable_vectors  src/lib.rs:1002-1037 */
+uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t lft, orc_search_params sp, uint64_t **out,
+                                  int threads) {
+  uint64_t n = ix->layers[lft].node_count;
+  uint64_t *hit = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+  orc_discover_hits(ix, lft, sp, 0, n, hit, threads);
+  uint64_t c = discover_filter(ix, lft, hit, out);
+  free(hit);
+  return c;
 }
 
 /* extend_layer  src/lib.rs:1039-1068 with generate_node_maps :1767-1812,
@@ -782,11 +795,21 @@ static orc_index *generate_impl(const float *rows, uint64_t n_store, uint32_t di
                                 const orc_store *pq_from, const uint64_t *vids, uint64_t n,
                                 const orc_build_params *bp, int threads);
 
+static int promote_impl(orc_index *ix, uint32_t lft, const orc_build_params *bp, const uint64_t *hit, int threads);
 /* promote_at_layer  src/lib.rs:1273-1427 */
 int orc_promote_at_layer(orc_index *ix, uint32_t lft, const orc_build_params *bp, int threads) {
+  return promote_impl(ix, lft, bp, NULL, threads);
+}
+/* ... from precomputed self-hit flags (the sharded drivers all-gather them) */
+int orc_promote_at_layer_hits(orc_index *ix, uint32_t lft, const orc_build_params *bp, const uint64_t *hit,
+                              int threads) {
+  return promote_impl(ix, lft, bp, hit, threads);
+}
+static int promote_impl(orc_index *ix, uint32_t lft, const orc_build_params *bp, const uint64_t *hit, int threads) {
   float max_proportion = bp->optimization.promotion_proportion;
   uint64_t *vecs = NULL;
-  uint64_t nv = orc_discover_unreachable(ix, lft, bp->optimization.search, &vecs, threads);
+  uint64_t nv = hit ? discover_filter(ix, lft, hit, &vecs)
+                    : orc_discover_unreachable(ix, lft, bp->optimization.search, &vecs, threads);
   if (nv == 0) {
     free(vecs);
     return 0;

@@ -82,6 +82,8 @@ SYMBOLS = {
     "phnsw_layer_finish_device": (_i32, [_vp, _vp, _vp]),
     "phnsw_link_search_device": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, _u64, _u64, _vp, _vp, _vp]),
     "phnsw_link_apply_device": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "phnsw_discover_hits_device": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, _u64, _vp]),
+    "phnsw_promote_at_layer_hits_device": (_i32, [_vp, _u32, C.POINTER(BuildParams), _vp, C.POINTER(_i32)]),
     "phnsw_recall_hits": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), _u64, _u64, C.POINTER(_u64),
                                  C.POINTER(_u64)]),
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),

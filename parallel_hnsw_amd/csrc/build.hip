@@ -1058,51 +1058,50 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
 // discover_unreachable_vectors  lib.rs:1002-1037: nodes of layer `lft` that a search over
 // layers[0..=lft] does not return among its leading |d| < 1e-5 results
 // (match_within_epsilon search.rs:173-187) and that are not in the layer above
-static int discover_unreachable_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp,
-                                     std::vector<uint32_t> &out) {
-  if (lft >= ix->layers.size()) {
-    ph_set_error("discover_unreachable: layer %u out of range", lft);
+// phase 1: self-hit flags (epsilon form) of nodes [first, first+count) of layer lft
+static int discover_hits_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp, uint32_t first,
+                              uint32_t count, uint32_t *hit_dev) {
+  if (lft >= ix->layers.size() || first + (uint64_t)count > ix->layers[lft].n_nodes) {
+    ph_set_error("discover_unreachable: layer %u / range out of bounds", lft);
     return PHNSW_E_INVALID;
   }
+  if (count == 0) return 0;
   PhLayerHost &L = ix->layers[lft];
-  PhTimer tm("discover_unreachable", L.n_nodes);
-  uint32_t n = L.n_nodes;
-  DevBuf<uint32_t> ids, len, hit;
+  PhTimer tm("discover_unreachable", count);
+  DevBuf<uint32_t> ids, len, status;
   DevBuf<float> d;
-  PH_TRY(ids.alloc(n));
-  PH_TRY(d.alloc(n));
-  PH_TRY(len.alloc(n));
-  PH_TRY(hit.alloc(n));
-  // search_stored with the epsilon form of the hit flag
-  {
-    DevBuf<uint32_t> status;
-    PH_TRY(status.alloc(n));
-    uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
-    bool done = false;
-    for (int attempt = 0; attempt < 3 && !done; attempt++) {
-      PH_TRY(ph_search_device(ix, nullptr, 0, L.nodes, n, sp, lft + 1, nullptr, ids.p, d.p, len.p, nullptr, status.p,
-                              ovf_cap, 0, 0, 1, hit.p, 0.f, 0, 1e-5f));
-      PH_HIP(hipDeviceSynchronize());
-      std::vector<uint32_t> hs(n);
-      PH_HIP(hipMemcpy(hs.data(), status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-      bool overflow = false;
-      for (uint32_t x : hs) {
-        if (x == 4) {
-          ph_set_error("discover_unreachable: layers are not nested");
-          return PHNSW_E_MISSING_NODE;
-        }
-        overflow |= x == 5;
+  PH_TRY(ids.alloc(count));
+  PH_TRY(d.alloc(count));
+  PH_TRY(len.alloc(count));
+  PH_TRY(status.alloc(count));
+  uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+  for (int attempt = 0; attempt < 3; attempt++) {
+    PH_TRY(ph_search_device(ix, nullptr, 0, L.nodes + first, count, sp, lft + 1, nullptr, ids.p, d.p, len.p, nullptr,
+                            status.p, ovf_cap, 0, 0, 1, hit_dev, 0.f, 0, 1e-5f));
+    PH_HIP(hipDeviceSynchronize());
+    std::vector<uint32_t> hs(count);
+    PH_HIP(hipMemcpy(hs.data(), status.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    bool overflow = false;
+    for (uint32_t x : hs) {
+      if (x == 4) {
+        ph_set_error("discover_unreachable: layers are not nested");
+        return PHNSW_E_MISSING_NODE;
       }
-      done = !overflow;
-      ovf_cap *= 8;
+      overflow |= x == 5;
     }
-    if (!done) {
-      ph_set_error("discover_unreachable: frontier spill overflow");
-      return PHNSW_E_OVERFLOW;
-    }
+    if (!overflow) return 0;
+    ovf_cap *= 8;
   }
+  ph_set_error("discover_unreachable: frontier spill overflow");
+  return PHNSW_E_OVERFLOW;
+}
+
+// phase 2: the vectors that did not find themselves and are not in the layer above
+static int discover_filter_impl(phnsw_index *ix, uint32_t lft, const uint32_t *hit_dev, std::vector<uint32_t> &out) {
+  PhLayerHost &L = ix->layers[lft];
+  uint32_t n = L.n_nodes;
   std::vector<uint32_t> h(n), nodes(n), above;
-  PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PH_HIP(hipMemcpy(h.data(), hit_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
   PH_HIP(hipMemcpy(nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
   if (lft > 0) {
     above.resize(ix->layers[lft - 1].n_nodes);
@@ -1112,6 +1111,18 @@ static int discover_unreachable_impl(phnsw_index *ix, uint32_t lft, const phnsw_
   for (uint32_t i = 0; i < n; i++)
     if (!h[i] && (lft == 0 || !std::binary_search(above.begin(), above.end(), nodes[i]))) out.push_back(nodes[i]);
   return 0;
+}
+
+static int discover_unreachable_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_params *sp,
+                                     std::vector<uint32_t> &out) {
+  if (lft >= ix->layers.size()) {
+    ph_set_error("discover_unreachable: layer %u out of range", lft);
+    return PHNSW_E_INVALID;
+  }
+  DevBuf<uint32_t> hit;
+  PH_TRY(hit.alloc(ix->layers[lft].n_nodes));
+  PH_TRY(discover_hits_impl(ix, lft, sp, 0, ix->layers[lft].n_nodes, hit.p));
+  return discover_filter_impl(ix, lft, hit.p, out);
 }
 
 // extend_layer  lib.rs:1039-1068 (generate_node_maps :1767-1812, copy_old_neighborhoods :1737-1765,
@@ -1233,10 +1244,15 @@ static int filter_promotion_candidates_impl(phnsw_index *ix, uint32_t lft, const
 }
 
 // promote_at_layer  lib.rs:1273-1427
-static int promote_at_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_build_params *bp, int *promoted) {
+static int promote_at_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_build_params *bp, int *promoted,
+                                 const uint32_t *hit_dev = nullptr) {
   *promoted = 0;
   std::vector<uint32_t> vecs;
-  PH_TRY(discover_unreachable_impl(ix, lft, &bp->optimization.search, vecs));
+  if (hit_dev) {
+    if (lft >= ix->layers.size()) return PHNSW_E_INVALID;
+    PH_TRY(discover_filter_impl(ix, lft, hit_dev, vecs));
+  } else
+    PH_TRY(discover_unreachable_impl(ix, lft, &bp->optimization.search, vecs));
   if (vecs.empty()) return 0;
   const float max_proportion = bp->optimization.promotion_proportion;
   if (max_proportion < 1.0f) {  // :1288-1294
@@ -1528,6 +1544,22 @@ extern "C" int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, 
   PH_TRY(enter(ix));
   if (!bp || !out_promoted) return PHNSW_E_INVALID;
   return promote_at_layer_impl(ix, layer_from_top, bp, out_promoted);
+}
+
+// phase API: the searches of promote_at_layer for a node range, then the promotion itself from
+// the all-gathered flags
+extern "C" int phnsw_discover_hits_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
+                                          uint64_t first, uint64_t count, uint32_t *out_hit) {
+  PH_TRY(enter(ix));
+  if (!sp || !out_hit) return PHNSW_E_INVALID;
+  return discover_hits_impl(ix, layer_from_top, sp, (uint32_t)first, (uint32_t)count, out_hit);
+}
+extern "C" int phnsw_promote_at_layer_hits_device(phnsw_index *ix, uint32_t layer_from_top,
+                                                  const phnsw_build_params *bp, const uint32_t *hit,
+                                                  int *out_promoted) {
+  PH_TRY(enter(ix));
+  if (!bp || !hit || !out_promoted) return PHNSW_E_INVALID;
+  return promote_at_layer_impl(ix, layer_from_top, bp, out_promoted, hit);
 }
 
 extern "C" int phnsw_discover_unreachable(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,

@@ -144,6 +144,15 @@ class GpuEngine:
     def promote_at_layer(self, lft):
         return self.hnsw.promote_at_layer(lft, self.bp)
 
+    def discover_hits(self, lft, sp, first, count, hit):
+        check(lib().phnsw_discover_hits_device(self.hnsw._h, lft, C.byref(sp), first, count, self._ptr(hit)))
+
+    def promote_from_hits(self, lft, hit):
+        out = C.c_int()
+        check(lib().phnsw_promote_at_layer_hits_device(self.hnsw._h, lft, C.byref(self.bp), self._ptr(hit),
+                                                       C.byref(out)))
+        return bool(out.value)
+
 
 class ShardedBuilder:
     """Hnsw::generate with every per-node phase split over the ranks of `comm`"""
@@ -214,8 +223,18 @@ class ShardedBuilder:
                 break
         return float(last)
 
-    # improve_index_at  lib.rs:1546-1603.  promote_at_layer runs replicated on every rank (its
-    # searches are a small share of a build and the replicas must stay identical).
+    # promote_at_layer  lib.rs:1273-1427: its n searches (discover_unreachable_vectors) are
+    # sharded like a link round, the (integer, sequential) promotion itself runs replicated
+    def promote_at_layer(self, lft):
+        if not hasattr(self.e, "discover_hits"):
+            return self.e.promote_at_layer(lft)
+        n = self.e.layer_nodes(lft)
+        chunk, first, count = self._range(n)
+        hit = self.e.empty((chunk,), "id")
+        self.e.discover_hits(lft, self.bp.optimization.search, first, count, hit)
+        return self.e.promote_from_hits(lft, self._gather(hit, n).contiguous())
+
+    # improve_index_at  lib.rs:1546-1603
     def improve_index_at(self, lft):
         op = self.bp.optimization
         recall = np.float32(self.stochastic_recall_at(lft))
@@ -228,7 +247,7 @@ class ShardedBuilder:
                 if recall == np.float32(1.0):
                     cur += 1
                     continue
-                if self.bp.promote and self.e.promote_at_layer(cur):
+                if self.bp.promote and self.promote_at_layer(cur):
                     delta = self.e.layer_count() - layer_count
                     cur += delta
                     lft += delta

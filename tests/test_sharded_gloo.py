@@ -71,6 +71,12 @@ class OracleEngine:
     def promote_at_layer(self, lft):
         return self.ix.promote_at_layer(lft, self.bp, threads=self.threads) > 0
 
+    def discover_hits(self, lft, sp, first, count, hit):
+        assert self.L.orc_discover_hits(self.ix.h, lft, sp, first, count, self._p(hit), self.threads) == 0
+
+    def promote_from_hits(self, lft, hit):
+        return self.L.orc_promote_at_layer_hits(self.ix.h, lft, C.byref(self.bp), self._p(hit), self.threads) > 0
+
     def recall_hits(self, at, op, first, count):
         hits, sel = C.c_uint64(), C.c_uint64()
         assert self.L.orc_recall_hits(self.ix.h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel),
