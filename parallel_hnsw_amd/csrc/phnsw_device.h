@@ -147,25 +147,26 @@ template <int NV>
 __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
                                                  bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
                                                  uint32_t lane) {
+  // 4 rows in flight per wave (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster)
+  constexpr int U = 4;
   float myd = 0.f;
   uint64_t rem = mask;
   while (rem) {
-    int l[4];
+    int l[U];
     l[0] = __builtin_ctzll(rem);
     rem &= rem - 1;
 #pragma unroll
-    for (int u = 1; u < 4; u++) {
+    for (int u = 1; u < U; u++) {
       l[u] = rem ? __builtin_ctzll(rem) : l[0];  // short tail: recompute row l[0] (same value)
       rem &= rem ? rem - 1 : 0;
     }
-    const float4 *r[4];
+    const float4 *r[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) r[u] = (const float4 *)(vecs + (uint64_t)rl32(vid, l[u]) * ld);
-    const float4 *const rr[4] = {r[0], r[1], r[2], r[3]};
-    float p[4];
-    rows_partial<NV, 4>(rr, qv, nv4, lane, l2, p);
+    for (int u = 0; u < U; u++) r[u] = (const float4 *)(vecs + (uint64_t)rl32(vid, l[u]) * ld);
+    float p[U];
+    rows_partial<NV, U>(r, qv, nv4, lane, l2, p);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       float d = finalize_metric(wave_sum(p[u]), metric);
       if ((int)lane == l[u]) myd = d;
     }
