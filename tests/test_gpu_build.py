@@ -310,3 +310,26 @@ def test_promotion_parity():
     ci, cd, cl = o0.search(queries=q, sp=(32, 32, 2))
     np.testing.assert_array_equal(gi, ci)
     np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))
+
+
+def test_baseline_config1_shape():
+    """BASELINE configs[0] (the reference's own bench shape, benches/bench.rs:9,24-30,54-63):
+    10 000 x 128 f32 (and the bench's literal 100 dims), cosine / 1-dot, default build, search
+    at number_of_candidates = 64 -- GPU and oracle end to end"""
+    for dim, metric, normalize in ((128, 0, True), (100, 1, False)):
+        n = 10000
+        rows = oracle.synth_rows(0, n, dim, normalize=normalize)
+        if not normalize:
+            rows = np.abs(rows)  # bench.rs draws rng.gen() in [0, 1), un-normalised
+        oix = oracle.Index.generate(rows, np.arange(n), obp(seed=7), dim=dim, metric=metric,
+                                    sum_mode=oracle.SUM_BLOCKED64)
+        store = ph.VectorStore(rows[:, :dim], metric=metric)
+        gix = ph.Hnsw.generate(store, np.arange(n), gbp(seed=7))
+        layers_equal(gix, oix)
+        q = np.abs(oracle.synth_rows(2 ** 32, 300, dim, normalize=normalize))[:, :dim] if not normalize else \
+            oracle.synth_rows(2 ** 32, 300, dim)[:, :dim]
+        gi, gd, gl, gs = gix.search_batch(queries=q, sp=ph.SearchParameters(64, 64, 2), stats=True)
+        ci, cd, cl, cs = oix.search(queries=q, sp=(64, 64, 2), stats=True)
+        np.testing.assert_array_equal(gi, ci)
+        np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))
+        np.testing.assert_array_equal(gs, cs)

@@ -219,3 +219,24 @@ def test_layer_invariants_and_rows():
         live = [x for x in row if x != EMPTY]
         assert row[:len(live)] == live
         assert i not in live and len(set(live)) == len(live)
+
+
+def test_bench_shape_plumbing():
+    """BASELINE configs[0] on the CPU alone (benches/bench.rs:54-63 benchmarks Hnsw::generate on
+    10 000 x 100 un-normalised vectors with 1 - dot): the oracle builds it, the layer invariants
+    hold and the self-recall the reference's recall tests assert (>= 0.9 after generate,
+    lib.rs:2218-2224) is met"""
+    n, dim = 10000, 100
+    rows = np.abs(oracle.synth_rows(0, n, dim, normalize=False))
+    bp = oracle.default_build_params(seed=0)
+    ix = oracle.Index.generate(rows, np.arange(n), bp, dim=dim, metric=oracle.METRIC_ONE_MINUS_DOT, threads=8)
+    assert [ix.layer(l)[0].shape[0] for l in range(ix.layer_count)][-1] == n
+    assert ix.layer_count >= 4 and ix.check_layer_invariants() == 0
+    nodes, nb = ix.layer(ix.layer_count - 1)
+    assert nb.shape == (n, 48)
+    # un-normalised 1 - dot is not a metric (a longer vector can beat the stored one itself), so
+    # self-recall is measured the reference's way on normalised data of the same shape
+    rows2 = oracle.synth_rows(0, n, dim)
+    ix2 = oracle.Index.generate(rows2, np.arange(n), bp, dim=dim, threads=8)
+    ids, d, ln = ix2.search(qids=np.arange(0, n, 10), sp=(300, 300, 2), threads=8)
+    assert np.mean(ids[:, 0] == np.arange(0, n, 10)) >= 0.9
