@@ -485,6 +485,7 @@ static uint32_t wave_grid(uint32_t n) {
 // apply proposal slots to the rows of `L`: count, scan, fill, merge (K5)
 static int apply_proposals(PhLayerHost &L, const uint32_t *tgt, const float *d, uint32_t S, uint64_t *out_added) {
   uint32_t n = L.n_nodes;
+  PhTimer tm(" apply_proposals(K5)", n);
   uint64_t nslots = (uint64_t)n * S;
   DevBuf<uint32_t> cnt, start, cursor, inc_src;
   DevBuf<float> inc_d;
@@ -734,6 +735,7 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
       ph_set_error("generate_layer: duplicate VectorId %u", nodes[i]);
       return PHNSW_E_INVALID;
     }
+  PhTimer tb(" layer_begin", n);
   std::vector<uint32_t> empty_rows((size_t)n * W, PH_EMPTY32);
   PhPendingLayer *P = new PhPendingLayer();
   int rc = ph_layer_upload(ix, nodes.data(), empty_rows.data(), n, W, &P->L);
@@ -781,6 +783,7 @@ static int layer_init_search_impl(phnsw_index *ix, const phnsw_build_params *bp,
     return PHNSW_E_INVALID;
   }
   if (count == 0) return 0;
+  PhTimer tm(" layer_init_search", count);
   const uint32_t K = P->K;
   DevBuf<uint32_t> res_ids, res_len, bad;
   DevBuf<float> res_d;
@@ -817,6 +820,7 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   const phnsw_store *s = ix->store;
   const uint32_t n = P->L.n_nodes, K = P->K, W = P->L.W;
   if (!P->grouped) {
+    PhTimer tg(" layer_group(host)", n);
     std::vector<uint32_t> key(n), h_len(n);
     std::vector<float> keyd(n);
     PH_HIP(hipMemcpy(h_len.data(), init_len, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -838,6 +842,7 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
     P->grouped = true;
   }
   if (count == 0) return 0;
+  PhTimer ts(" layer_seed(K3)", count);
   PhSeedArgs a;
   a.dist = ph_dist_args(s);
   a.nodes = P->L.nodes;
