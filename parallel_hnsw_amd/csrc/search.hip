@@ -592,6 +592,9 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
+  // launches share the per-wave workspace (visited bitmaps, spill lists): order a launch on
+  // another stream behind the previous one
+  if (ws.timed) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
   PH_HIP(hipMemsetAsync(ws.counter, 0, 4, stream));
   PH_HIP(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc, pq_lds), stream, a);
