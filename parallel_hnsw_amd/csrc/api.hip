@@ -426,7 +426,8 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   hipSetDevice(ix->store->device);
   for (auto &l : ix->layers) ph_layer_free(l);
   ph_pending_free(ix);
-  ph_workspace_free(ix->ws);
+  ph_workspace_free(ix->ws[0]);
+  ph_workspace_free(ix->ws[1]);
   phnsw_store_destroy(ix->store);
   delete ix;
 }
@@ -527,9 +528,12 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.hit_eps = hit_eps;
   a.cap_max = knn_mode == 2 ? out_stride : 0;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
-  int rc = ph_workspace_ensure(ix, mix->ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
+  PhWorkspace &ws = mix->ws[mix->ws_next & 1];
+  mix->ws_last = mix->ws_next & 1;
+  mix->ws_next++;
+  int rc = ph_workspace_ensure(ix, ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;
-  return ph_search_launch(ix, mix->ws, a, stream);
+  return ph_search_launch(ix, ws, a, stream);
 }
 
 extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq,
@@ -554,12 +558,13 @@ extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
   if (!ix || !ms) return PHNSW_E_INVALID;
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   std::lock_guard<std::mutex> g(mix->ws_mutex);
-  if (!mix->ws.timed) {
+  PhWorkspace &ws = mix->ws[mix->ws_last];
+  if (!ws.timed) {
     ph_set_error("no search has been launched on this index");
     return PHNSW_E_INVALID;
   }
-  PH_HIP(hipEventSynchronize(mix->ws.ev1));
-  PH_HIP(hipEventElapsedTime(ms, mix->ws.ev0, mix->ws.ev1));
+  PH_HIP(hipEventSynchronize(ws.ev1));
+  PH_HIP(hipEventElapsedTime(ms, ws.ev0, ws.ev1));
   return 0;
 }
 

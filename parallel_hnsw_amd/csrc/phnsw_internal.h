@@ -89,7 +89,10 @@ struct phnsw_index {
   std::vector<PhLayerHost> layers;  // top first (src/lib.rs:587)
   phnsw_build_params bp;
   std::mutex ws_mutex;
-  PhWorkspace ws;
+  // two workspaces, used alternately: launches on different streams may overlap (the tail of
+  // one batch with the head of the next); a third launch waits for the first
+  PhWorkspace ws[2];
+  uint32_t ws_next = 0, ws_last = 0;
   float last_kernel_ms = 0.f;
 };
 
