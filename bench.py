@@ -203,8 +203,13 @@ def main():
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         runs = [run, run_b]
 
+        one_stream = bool(os.environ.get("BENCH_ONE_STREAM"))
+
         def step(i):
-            runs[i & 1].launch(sp, streams[i & 1].cuda_stream)
+            if one_stream:
+                run.launch(sp)
+            else:
+                runs[i & 1].launch(sp, streams[i & 1].cuda_stream)
 
         for i in range(args.warmup):
             step(i)
