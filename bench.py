@@ -199,8 +199,11 @@ def main():
         gt = ground_truth(base_t, tensor_of(qstore))
         # steps are issued on two streams alternately (two workspaces inside the library): the
         # tail of one batch overlaps the head of the next, like back-to-back batches in serving
+        torch.cuda.synchronize()  # ground truth (default stream) done before side streams touch memory
         run_b = Runner(index, qstore, ef_max=ef)
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
         runs = [run, run_b]
 
         one_stream = bool(os.environ.get("BENCH_ONE_STREAM"))
