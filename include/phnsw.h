@@ -275,6 +275,16 @@ int phnsw_index_build_params(const phnsw_index *ix, phnsw_build_params *bp);
 int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
               float *out_d, uint64_t *out_len);
 
+/* ---- exact k nearest neighbours by brute force: the ground truth for recall@k (the reference
+ * only measures self-recall, lib.rs:1485-1496).  A true GEMM (queries x base rows) on the f32
+ * MFMA units, exact f32 with a k-ordered fma chain per score; dot-product metrics, k <= 16.
+ * Results sorted by (distance, id). ---- */
+int phnsw_bruteforce_topk(const phnsw_store *s, const float *queries, uint64_t nq, uint32_t k,
+                          uint64_t *out_ids, float *out_d);
+int phnsw_bruteforce_topk_device(const phnsw_store *s, const float *queries_dev, uint32_t ldq, uint64_t nq,
+                                 uint32_t k, uint32_t *out_ids_dev, float *out_d_dev, void *stream);
+float phnsw_bruteforce_last_gemm_ms(void); /* MFMA GEMM time of this thread's last pass */
+
 /* Hnsw::threshold_nn  src/lib.rs:930-962 : bottom layer; out [node_count][max_out], entries
  * with distance < threshold, self removed; the device queue may double up to 1024 entries */
 int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,

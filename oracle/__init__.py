@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
 FMAX = np.float32(3.4028234663852886e38)
 METRIC_COSINE_HALF, METRIC_ONE_MINUS_DOT, METRIC_L2 = 0, 1, 2
-SUM_SEQ, SUM_BLOCKED64 = 0, 1
+SUM_SEQ, SUM_BLOCKED64, SUM_SEQFMA = 0, 1, 2
 
 
 def build_lib(force=False):

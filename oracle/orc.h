@@ -41,7 +41,9 @@ enum {
  * BLOCKED64 is the order the gfx950 kernel uses (one fma chain per lane of a 64-lane
  * wavefront over 16-byte chunks l, l+64, ..., then an xor-butterfly 32,16,..,1), so the
  * HIP path can be checked bit-exactly; see DESIGN.md "summation order". */
-enum { ORC_SUM_SEQ = 0, ORC_SUM_BLOCKED64 = 1 };
+/* SEQFMA: sequential like the reference but with one rounding per step (fmaf chain) -- the
+ * order of the f32 MFMA units, used by the brute-force ground-truth kernel */
+enum { ORC_SUM_SEQ = 0, ORC_SUM_BLOCKED64 = 1, ORC_SUM_SEQFMA = 2 };
 
 typedef struct {
   const float *rows; /* [n * ld], row i at rows + i*ld, floats dim..ld-1 are zero */

@@ -55,9 +55,23 @@ static float acc_blocked64(const orc_store *s, const float *a, const float *b) {
   return acc[0];
 }
 
+static float acc_seqfma(const orc_store *s, const float *a, const float *b) {
+  float r = 0.0f;
+  if (s->metric == ORC_METRIC_L2) {
+    for (uint32_t i = 0; i < s->dim; i++) {
+      float d = a[i] - b[i];
+      r = fmaf(d, d, r);
+    }
+  } else {
+    for (uint32_t i = 0; i < s->dim; i++) r = fmaf(a[i], b[i], r);
+  }
+  return r;
+}
+
 /* Comparator::compare_raw  (src/lib.rs:59) for the three in-tree metrics */
 float orc_distance(const orc_store *s, const float *a, const float *b) {
-  float r = (s->sum_mode == ORC_SUM_BLOCKED64) ? acc_blocked64(s, a, b) : acc_seq(s, a, b);
+  float r = (s->sum_mode == ORC_SUM_BLOCKED64) ? acc_blocked64(s, a, b)
+            : (s->sum_mode == ORC_SUM_SEQFMA) ? acc_seqfma(s, a, b) : acc_seq(s, a, b);
   switch (s->metric) {
     case ORC_METRIC_COSINE_HALF:
       return (1.0f - r) / 2.0f; /* src/bigvec.rs:52 */

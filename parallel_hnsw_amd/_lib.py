@@ -96,6 +96,9 @@ SYMBOLS = {
     "phnsw_index_serialize": (_i32, [_vp, C.c_char_p]),
     "phnsw_index_deserialize": (_i32, [_vp, C.c_char_p, _pp]),
     "phnsw_index_build_params": (_i32, [_vp, C.POINTER(BuildParams)]),
+    "phnsw_bruteforce_topk": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp]),
+    "phnsw_bruteforce_topk_device": (_i32, [_vp, _vp, _u32, _u64, _u32, _vp, _vp, _vp]),
+    "phnsw_bruteforce_last_gemm_ms": (_f32, []),
     "phnsw_threshold_nn": (_i32, [_vp, _f32, _u64, _u64, _u64, _vp, _vp, _vp]),
     "phnsw_knn": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
 }

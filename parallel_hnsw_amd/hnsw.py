@@ -100,6 +100,20 @@ class VectorStore:
         check(lib().phnsw_store_read(self._h, first, count, _p(out)))
         return out
 
+    def bruteforce_topk(self, queries, k=10):
+        """exact k nearest by (distance, id): MFMA GEMM + top-k (ground truth for recall@k)"""
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        assert q.shape[1] == self.dim
+        ids = np.empty((q.shape[0], k), dtype=np.uint64)
+        d = np.empty((q.shape[0], k), dtype=np.float32)
+        check(lib().phnsw_bruteforce_topk(self._h, _p(q), q.shape[0], k, _p(ids), _p(d)))
+        return ids, d
+
+    def bruteforce_topk_device(self, queries_ptr, ldq, nq, k, out_ids_ptr, out_d_ptr, stream=0):
+        check(lib().phnsw_bruteforce_topk_device(self._h, C.c_void_p(queries_ptr), ldq, nq, k, C.c_void_p(out_ids_ptr),
+                                                 C.c_void_p(out_d_ptr), C.c_void_p(stream or None)))
+        return lib().phnsw_bruteforce_last_gemm_ms()
+
     def compare_vec(self, v, ids):
         """Comparator::compare_vec batched (lib.rs:69-73): distances from v to Stored(ids)"""
         ids = np.ascontiguousarray(ids, dtype=np.uint64)

@@ -208,3 +208,22 @@ def test_frontier_spill_path():
         cpu = oix.search(queries=q, sp=(ef, ef, pd), stats=True)
         assert_same(gpu, cpu)
         np.testing.assert_array_equal(gpu[3], cpu[3])
+
+
+@pytest.mark.parametrize("n,dim,metric,k", [(5000, 768, 0, 10), (3000, 100, 1, 16), (700, 3, 0, 1), (129, 32, 0, 5)])
+def test_bruteforce_mfma_exact(n, dim, metric, k):
+    """G1 ground truth: f32 MFMA GEMM + top-k == the oracle's exact kNN in sequential-fma order,
+    bit for bit (ids and distances), and == the reference's sequential order up to near ties"""
+    rows = oracle.synth_rows(0, n, dim)
+    store = ph.VectorStore(rows[:, :dim], metric=metric)
+    q = oracle.synth_rows(2 ** 32, 300, dim)[:, :dim]
+    gi, gd = store.bruteforce_topk(q, k)
+    oix = oracle.Index(rows, dim=dim, metric=metric)
+    ci, cd = oix.bruteforce(q, k, sum_mode=oracle.SUM_SEQFMA)
+    np.testing.assert_array_equal(gi, ci)
+    np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))
+    si, sd = oix.bruteforce(q, k, sum_mode=oracle.SUM_SEQ)
+    assert (gi == si).mean() > 0.99
+    np.testing.assert_allclose(gd, sd, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ph.PhnswError):
+        ph.VectorStore(rows[:, :dim], metric=2).bruteforce_topk(q, k)  # L2 is not a GEMM here
