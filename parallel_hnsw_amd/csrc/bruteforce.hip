@@ -48,14 +48,17 @@ __global__ __launch_bounds__(256) void ph_gemm_nt_mfma_kernel(const float *__res
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const uint32_t lrow = t >> 3, lk = (t & 7) * 4;    // loader: 32 rows x 8 float4 per pass, 4 passes
-  for (uint32_t k0 = 0; k0 < K; k0 += BF_TK) {
-    float4 qa[4], ba[4];
+  float4 qa[4], ba[4];
+  auto load_stage = [&](uint32_t k0) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       uint32_t row = lrow + 32 * p, kk = k0 + lk;
       qa[p] = (q0 + row < nq && kk < K) ? *(const float4 *)(Q + (uint64_t)(q0 + row) * ldq + kk) : make_float4(0, 0, 0, 0);
       ba[p] = (b0 + row < nb && kk < K) ? *(const float4 *)(B + (uint64_t)(b0 + row) * ldb + kk) : make_float4(0, 0, 0, 0);
     }
+  };
+  load_stage(0);
+  for (uint32_t k0 = 0; k0 < K; k0 += BF_TK) {
     __syncthreads();  // the previous stage's fragment reads are done
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void ph_gemm_nt_mfma_kernel(const float *__res
       Bs[lk + 3][row] = ba[p].w;
     }
     __syncthreads();
+    if (k0 + BF_TK < K) load_stage(k0 + BF_TK);  // in flight under this stage's MFMAs
     // A operand = queries: lane l supplies A[i = l&31][k = l>>5]; B operand = base rows:
     // B[k = l>>5][j = l&31]; k ascends through the loop => one fma chain per output element
 #pragma unroll
