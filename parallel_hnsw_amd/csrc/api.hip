@@ -305,6 +305,7 @@ void ph_layer_free(PhLayerHost &l) {
   if (l.neighbors) hipFree(l.neighbors);
   if (l.nbr_dist) hipFree(l.nbr_dist);
   if (l.vec2node) hipFree(l.vec2node);
+  if (l.recall_q) hipFree(l.recall_q);
   l = PhLayerHost();
 }
 
@@ -318,10 +319,18 @@ int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neig
   hipError_t e = hipMalloc(&l.nodes, (size_t)n * 4);
   if (e == hipSuccess) e = hipMalloc(&l.neighbors, (size_t)n * W * 4);
   if (e == hipSuccess) e = hipMemcpy(l.nodes, nodes, (size_t)n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(l.neighbors, neighbors, (size_t)n * W * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && neighbors)
+    e = hipMemcpy(l.neighbors, neighbors, (size_t)n * W * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     ph_layer_free(l);
     return ph_hip_fail(e, "layer upload", __FILE__, __LINE__);
+  }
+  if (!neighbors) {  // all rows empty
+    int rc = ph_fill_u32(l.neighbors, PH_EMPTY32, (uint64_t)n * W, 0);
+    if (rc) {
+      ph_layer_free(l);
+      return rc;
+    }
   }
   bool identity = true;
   for (uint32_t i = 0; i < n; i++)

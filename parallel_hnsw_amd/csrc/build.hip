@@ -681,6 +681,9 @@ static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &no
 // phases (parallel_hnsw_amd/sharded.py); the single-GPU entry point runs the same phases
 // over the whole range.
 
+int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const uint32_t *init_len, uint32_t K,
+                           uint32_t n, uint32_t *gm, uint32_t *gstart, uint32_t *gsize);  // group.hip
+
 struct PhPendingLayer {
   PhLayerHost L;
   uint32_t K = 0;
@@ -736,9 +739,8 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
       return PHNSW_E_INVALID;
     }
   PhTimer tb(" layer_begin", n);
-  std::vector<uint32_t> empty_rows((size_t)n * W, PH_EMPTY32);
   PhPendingLayer *P = new PhPendingLayer();
-  int rc = ph_layer_upload(ix, nodes.data(), empty_rows.data(), n, W, &P->L);
+  int rc = ph_layer_upload(ix, nodes.data(), nullptr, n, W, &P->L);  // rows start empty
   if (!rc) {
     hipError_t e = hipMalloc(&P->L.nbr_dist, (size_t)n * W * 4);
     if (e != hipSuccess) rc = ph_hip_fail(e, "nbr_dist alloc", __FILE__, __LINE__);
@@ -820,25 +822,11 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   const phnsw_store *s = ix->store;
   const uint32_t n = P->L.n_nodes, K = P->K, W = P->L.W;
   if (!P->grouped) {
-    PhTimer tg(" layer_group(host)", n);
-    std::vector<uint32_t> key(n), h_len(n);
-    std::vector<float> keyd(n);
-    PH_HIP(hipMemcpy(h_len.data(), init_len, (size_t)n * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy2D(key.data(), 4, init_ids, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy2D(keyd.data(), 4, init_d, (size_t)K * 4, 4, n, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; i++)
-      if (h_len[i] == 0) {
-        key[i] = PH_EMPTY32;
-        keyd[i] = 0.f;
-      }
-    std::vector<uint32_t> gm, gstart, gsize;
-    build_groups(n, key, keyd, gm, gstart, gsize);  // lib.rs:711-713
+    PhTimer tg(" layer_group", n);
     PH_TRY(P->gm.alloc(n));
     PH_TRY(P->gstart.alloc(n + 1));
     PH_TRY(P->gsize.alloc(n + 1));
-    PH_HIP(hipMemcpy(P->gm.p, gm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    PH_HIP(hipMemcpy(P->gstart.p, gstart.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
-    PH_HIP(hipMemcpy(P->gsize.p, gsize.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    PH_TRY(ph_build_groups_device(init_ids, init_d, init_len, K, n, P->gm.p, P->gstart.p, P->gsize.p));  // lib.rs:711-713
     P->grouped = true;
   }
   if (count == 0) return 0;
@@ -963,24 +951,34 @@ static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_par
   return link_apply_impl(ix, lft, link_count, res_ids.p, res_d.p, res_len.p, out_added);
 }
 
-// the sample of stochastic_recall_at  lib.rs:1468-1483
-static std::vector<uint32_t> recall_sample(phnsw_index *ix, uint32_t at, const phnsw_optimization_params *op, int *rc) {
-  const PhLayerHost &L = ix->layers[at];
+// the sample of stochastic_recall_at  lib.rs:1468-1483 (StdRng::seed_from_u64(42): the same
+// sample every call, so it is kept with the layer until its node list changes)
+static int recall_sample(phnsw_index *ix, uint32_t at, const phnsw_optimization_params *op, const uint32_t **out_dev,
+                         uint64_t *out_selection) {
+  PhLayerHost &L = ix->layers[at];
   uint64_t total = L.n_nodes;
   uint64_t selection = (uint64_t)((float)total * op->recall_proportion);
   selection = std::min<uint64_t>(std::max<uint64_t>(selection, 1), total);
-  std::vector<uint32_t> h_nodes(total);
-  hipError_t e = hipMemcpy(h_nodes.data(), L.nodes, total * 4, hipMemcpyDeviceToHost);
-  if (e != hipSuccess) {
-    *rc = ph_hip_fail(e, "recall sample", __FILE__, __LINE__);
-    return {};
+  *out_selection = selection;
+  if (selection == total) {
+    *out_dev = L.nodes;
+    return 0;
   }
-  std::vector<uint64_t> vecs(h_nodes.begin(), h_nodes.end());
-  if (selection != total) ph_shuffle_u64(vecs.data(), total, 42);  // StdRng::seed_from_u64(42)
-  std::vector<uint32_t> q(selection);
-  for (uint64_t i = 0; i < selection; i++) q[i] = (uint32_t)vecs[i];
-  *rc = 0;
-  return q;
+  if (!L.recall_q || L.recall_n != selection) {
+    std::vector<uint32_t> h_nodes(total);
+    PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, total * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> vecs(h_nodes.begin(), h_nodes.end());
+    ph_shuffle_u64(vecs.data(), total, 42);
+    std::vector<uint32_t> q(selection);
+    for (uint64_t i = 0; i < selection; i++) q[i] = (uint32_t)vecs[i];
+    if (L.recall_q) hipFree(L.recall_q);
+    L.recall_q = nullptr;
+    PH_HIP(hipMalloc(&L.recall_q, selection * 4));
+    PH_HIP(hipMemcpy(L.recall_q, q.data(), selection * 4, hipMemcpyHostToDevice));
+    L.recall_n = (uint32_t)selection;
+  }
+  *out_dev = L.recall_q;
+  return 0;
 }
 
 // hits among sample[first, first+count): self.search(Stored(vid), op.search) over the whole
@@ -991,24 +989,22 @@ static int recall_hits_impl(phnsw_index *ix, uint32_t at, const phnsw_optimizati
     ph_set_error("stochastic_recall_at: layer %u out of range", at);
     return PHNSW_E_INVALID;
   }
-  int rc = 0;
-  std::vector<uint32_t> q = recall_sample(ix, at, op, &rc);
-  if (rc) return rc;
-  if (out_selection) *out_selection = q.size();
-  if (first > q.size()) first = q.size();
-  if (first + count > q.size()) count = q.size() - first;
+  const uint32_t *q = nullptr;
+  uint64_t selection = 0;
+  PH_TRY(recall_sample(ix, at, op, &q, &selection));
+  if (out_selection) *out_selection = selection;
+  if (first > selection) first = selection;
+  if (first + count > selection) count = selection - first;
   *out_hits = 0;
   if (count == 0) return 0;
   uint32_t nq = (uint32_t)count;
-  DevBuf<uint32_t> qd, ids, len, hit;
+  DevBuf<uint32_t> ids, len, hit;
   DevBuf<float> d;
-  PH_TRY(qd.alloc(nq));
   PH_TRY(ids.alloc(nq));
   PH_TRY(d.alloc(nq));
   PH_TRY(len.alloc(nq));
   PH_TRY(hit.alloc(nq));
-  PH_HIP(hipMemcpy(qd.p, q.data() + first, (size_t)nq * 4, hipMemcpyHostToDevice));
-  PH_TRY(search_stored(ix, qd.p, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
+  PH_TRY(search_stored(ix, q + first, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
   std::vector<uint32_t> h(nq);
   PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
   uint64_t relevant = 0;
@@ -1105,6 +1101,7 @@ static int discover_hits_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_
 static int discover_filter_impl(phnsw_index *ix, uint32_t lft, const uint32_t *hit_dev, std::vector<uint32_t> &out) {
   PhLayerHost &L = ix->layers[lft];
   uint32_t n = L.n_nodes;
+  PhTimer tm(" discover_filter", n);
   std::vector<uint32_t> h(n), nodes(n), above;
   PH_HIP(hipMemcpy(h.data(), hit_dev, (size_t)n * 4, hipMemcpyDeviceToHost));
   PH_HIP(hipMemcpy(nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -1135,6 +1132,7 @@ static int discover_unreachable_impl(phnsw_index *ix, uint32_t lft, const phnsw_
 static int extend_layer_impl(phnsw_index *ix, uint32_t lft, std::vector<uint32_t> vecs) {
   PhLayerHost &L = ix->layers[lft];
   const uint32_t W = L.W, n_old = L.n_nodes;
+  PhTimer tm(" extend_layer", vecs.size());
   std::sort(vecs.begin(), vecs.end());
   std::vector<uint32_t> old_nodes(n_old), old_nb((size_t)n_old * W);
   std::vector<float> old_d;
@@ -1182,6 +1180,13 @@ static int extend_layer_impl(phnsw_index *ix, uint32_t lft, std::vector<uint32_t
   return 0;
 }
 
+__global__ void ph_gather_rows_kernel(const uint32_t *neighbors, uint32_t W, const uint32_t *which, uint32_t cnt,
+                                      uint32_t *out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)cnt * W) return;
+  out[i] = neighbors[(size_t)which[i / W] * W + (i % W)];
+}
+
 // filter_promotion_candidates  lib.rs:1176-1271.  Every unreachable vector of layer `lft`
 // is absent from the layer above, so (nesting invariant) its discover_order_from_top is
 // `lft`: one histogram.  Ties of the count sort (HashMap order in the reference) are
@@ -1192,51 +1197,96 @@ static int filter_promotion_candidates_impl(phnsw_index *ix, uint32_t lft, const
   if (lft == 0) return 0;
   const phnsw_store *s = ix->store;
   PhLayerHost &L = ix->layers[lft];
-  const uint32_t n = L.n_nodes, W = L.W;
-  std::vector<uint32_t> nodes(n), nb((size_t)n * W);
+  const uint32_t n = L.n_nodes, W = L.W, nv = (uint32_t)vecs.size();
+  PhTimer tm(" filter_promotion_candidates", vecs.size());
+  // only the rows of the unreachable nodes are needed on the host
+  std::vector<uint32_t> nodes(n), vnode(nv), nb((size_t)nv * W);
   PH_HIP(hipMemcpy(nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
-  PH_HIP(hipMemcpy(nb.data(), L.neighbors, nb.size() * 4, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> count(n, 0);
-  for (uint32_t v : vecs) {  // histogramming  :1190-1223
-    uint32_t node = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), v) - nodes.begin());
-    for (uint32_t k = 0; k < W; k++) {
-      uint32_t x = nb[(size_t)node * W + k];
-      if (x == PH_EMPTY32) break;
-      if (std::binary_search(vecs.begin(), vecs.end(), nodes[x])) count[x]++;
-    }
+  for (uint32_t i = 0; i < nv; i++)
+    vnode[i] = (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), vecs[i]) - nodes.begin());
+  {
+    DevBuf<uint32_t> which, rows;
+    PH_TRY(which.alloc(nv));
+    PH_TRY(rows.alloc((size_t)nv * W));
+    PH_HIP(hipMemcpy(which.p, vnode.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ph_gather_rows_kernel, dim3((uint32_t)(((uint64_t)nv * W + 255) / 256)), dim3(256), 0, 0,
+                       L.neighbors, W, which.p, nv, rows.p);
+    PH_HIP(hipGetLastError());
+    PH_HIP(hipMemcpy(nb.data(), rows.p, nb.size() * 4, hipMemcpyDeviceToHost));
   }
-  std::vector<std::pair<uint32_t, uint32_t>> histo;  // (count, node)
-  for (uint32_t i = 0; i < n; i++)
-    if (count[i]) histo.push_back({count[i], i});
+  std::vector<uint32_t> hit_nodes;
+  for (uint32_t i = 0; i < nv; i++)  // histogramming  :1190-1223
+    for (uint32_t k = 0; k < W; k++) {
+      uint32_t x = nb[(size_t)i * W + k];
+      if (x == PH_EMPTY32) break;
+      if (std::binary_search(vecs.begin(), vecs.end(), nodes[x])) hit_nodes.push_back(x);
+    }
+  std::sort(hit_nodes.begin(), hit_nodes.end());
+  std::vector<std::pair<uint32_t, uint32_t>> histo;  // (count, node), ascending; popped from the back
+  for (size_t i = 0; i < hit_nodes.size();) {
+    size_t j = i;
+    while (j < hit_nodes.size() && hit_nodes[j] == hit_nodes[i]) j++;
+    histo.push_back({(uint32_t)(j - i), hit_nodes[i]});
+    i = j;
+  }
   std::sort(histo.begin(), histo.end());
+  const uint32_t H = (uint32_t)histo.size();
+  if (H == 0) return 0;
+  std::vector<uint32_t> cand(H);  // in the order the reference pops them  :1243
+  for (uint32_t j = 0; j < H; j++) cand[j] = nodes[histo[H - 1 - j].second];
+  DevBuf<uint32_t> cand_d;
+  PH_TRY(cand_d.alloc(H));
+  PH_HIP(hipMemcpy(cand_d.p, cand.data(), (size_t)H * 4, hipMemcpyHostToDevice));
   std::vector<float> radius;
-  DevBuf<uint32_t> sel_d, one_id, one_len, one_status;
+  if (H <= 4096) {
+    // batched form: the index does not change while candidates are thinned, so every
+    // candidate's radius (search_upto(Stored(vec), sp, lft)[0].1  :1254-1259) and the H x H
+    // compare_vec table (:1244-1249) are computed up front; the sequential selection runs on them
+    DevBuf<uint32_t> r_id, r_len;
+    DevBuf<float> r_d, table;
+    PH_TRY(r_id.alloc(H));
+    PH_TRY(r_d.alloc(H));
+    PH_TRY(r_len.alloc(H));
+    PH_TRY(table.alloc((size_t)H * H));
+    PH_TRY(search_stored(ix, cand_d.p, H, sp, lft, nullptr, r_id.p, r_d.p, r_len.p, 1, nullptr));
+    for (uint32_t j = 0; j < H; j++)
+      PH_TRY(ph_distance_batch(s, nullptr, cand[j], cand_d.p, H, table.p + (size_t)j * H, 0));
+    std::vector<float> hr(H), ht((size_t)H * H);
+    std::vector<uint32_t> hl(H);
+    PH_HIP(hipMemcpy(hr.data(), r_d.p, (size_t)H * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(hl.data(), r_len.p, (size_t)H * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(ht.data(), table.p, ht.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> sel_j;
+    for (uint32_t j = 0; j < H; j++) {
+      bool covered = false;
+      for (size_t k = 0; k < sel_j.size() && !covered; k++) covered = ht[(size_t)j * H + sel_j[k]] < radius[k];
+      if (covered) continue;
+      sel_j.push_back(j);
+      sel.push_back(cand[j]);
+      radius.push_back(hl[j] ? hr[j] : 0.f);
+    }
+    return 0;
+  }
+  // many candidates: one at a time, as the reference does
+  DevBuf<uint32_t> sel_d, one_id, one_len;
   DevBuf<float> dist_d, one_d;
-  const uint32_t ef = (uint32_t)sp->number_of_candidates;
-  PH_TRY(sel_d.alloc(histo.size()));
-  PH_TRY(dist_d.alloc(histo.size()));
-  PH_TRY(one_id.alloc(ef));
-  PH_TRY(one_d.alloc(ef));
+  PH_TRY(sel_d.alloc(H));
+  PH_TRY(dist_d.alloc(H));
+  PH_TRY(one_id.alloc(1));
+  PH_TRY(one_d.alloc(1));
   PH_TRY(one_len.alloc(1));
-  PH_TRY(one_status.alloc(1));
-  DevBuf<uint32_t> qd;
-  PH_TRY(qd.alloc(1));
   std::vector<float> hd;
-  while (!histo.empty()) {  // while let Some((node, _)) = histogram.pop()  :1243
-    uint32_t vec = nodes[histo.back().second];
-    histo.pop_back();
+  for (uint32_t j = 0; j < H; j++) {
+    uint32_t vec = cand[j];
     bool covered = false;
-    if (!sel.empty()) {  // compare_vec(Stored(v), Stored(vec)) < radius for any selected v  :1244-1249
+    if (!sel.empty()) {
       PH_TRY(ph_distance_batch(s, nullptr, vec, sel_d.p, (uint32_t)sel.size(), dist_d.p, 0));
       hd.resize(sel.size());
       PH_HIP(hipMemcpy(hd.data(), dist_d.p, sel.size() * 4, hipMemcpyDeviceToHost));
       for (size_t k = 0; k < sel.size() && !covered; k++) covered = hd[k] < radius[k];
     }
     if (covered) continue;
-    // radius = self.search_upto(Stored(vec), sp, layer_from_top)[0].1  :1254-1259
-    PH_HIP(hipMemcpy(qd.p, &vec, 4, hipMemcpyHostToDevice));
-    PH_TRY(ph_search_device(ix, nullptr, 0, qd.p, 1, sp, lft, nullptr, one_id.p, one_d.p, one_len.p, nullptr,
-                            one_status.p, 0, 0, 0));
+    PH_TRY(search_stored(ix, cand_d.p + j, 1, sp, lft, nullptr, one_id.p, one_d.p, one_len.p, 1, nullptr));
     float r0 = 0.f;
     uint32_t l0 = 0;
     PH_HIP(hipMemcpy(&l0, one_len.p, 4, hipMemcpyDeviceToHost));
@@ -1294,6 +1344,7 @@ static int promote_at_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_buil
     nbp.zero_layer_neighborhood_size = bp->neighborhood_size;  // "a fake zero layer"  :1377-1379
     nbp.seed = bp->seed + 0x51ED270B9F3ULL + ix->layers.size();  // thread_rng in the reference
     phnsw_index *nt = nullptr;
+    PhTimer tr(" promote: rebuild top", top.size());
     PH_TRY(build_impl(ix->store, top.data(), top.size(), &nbp, nullptr, nullptr, &nt));
     std::vector<PhLayerHost> nl = nt->layers;
     nt->layers.clear();

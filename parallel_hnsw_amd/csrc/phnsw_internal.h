@@ -40,6 +40,8 @@ struct PhLayerHost {
   float *nbr_dist = nullptr;  // [n_nodes * W] distance of each occupant to the row owner (build only)
   uint32_t *vec2node = nullptr;
   bool identity = false;
+  uint32_t *recall_q = nullptr;  // cached stochastic_recall_at sample (build.hip), recall_n entries
+  uint32_t recall_n = 0;
 };
 
 // what a distance evaluation needs: the f32 store, or -- for a product-quantised store --
