@@ -306,7 +306,28 @@ void ph_layer_free(PhLayerHost &l) {
   if (l.nbr_dist) hipFree(l.nbr_dist);
   if (l.vec2node) hipFree(l.vec2node);
   if (l.recall_q) hipFree(l.recall_q);
+  if (l.pos) hipFree(l.pos);
+  if (l.ord) hipFree(l.ord);
   l = PhLayerHost();
+}
+
+// processing order of the node range [first, first + count) of a layer: argsort of the nodes'
+// positions, kept with the layer (build rounds repeat the same range).  *out = nullptr when
+// the layer has no positions or the range is too short to matter.
+int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const uint32_t **out) {
+  *out = nullptr;
+  if (!L.pos || count < PH_ORDER_MIN || getenv("PHNSW_NO_LOCALITY")) return 0;
+  if (!L.ord || L.ord_first != first || L.ord_count != count) {
+    if (L.ord) hipFree(L.ord);
+    L.ord = nullptr;
+    PH_HIP(hipMalloc(&L.ord, (size_t)count * 4));
+    int rc = ph_order_by_keys_device(L.pos + first, count, L.ord, 0);
+    if (rc) return rc;
+    L.ord_first = first;
+    L.ord_count = count;
+  }
+  *out = L.ord;
+  return 0;
 }
 
 // upload one layer (u32 device form) and derive the VectorId -> NodeId map that replaces
@@ -510,12 +531,15 @@ static void fill_args(const phnsw_index *ix, const phnsw_search_params *sp, uint
 
 static uint32_t default_ovf_cap(uint32_t ef) { return std::max<uint32_t>(8192u, ef * 64u); }
 
+static uint64_t g_two_launch_count = 0;  // tests check that the two-launch path really ran
+extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count; }
+
 // enqueue one search launch; caller owns all device buffers
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
-                     uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps) {
+                     uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps, const uint32_t *order) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -536,13 +560,39 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.first_node = first_node;
   a.hit_eps = hit_eps;
   a.cap_max = knn_mode == 2 ? out_stride : 0;
+  a.order = (ix->dbg_order && ix->dbg_order_n == nq) ? ix->dbg_order : order;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
   PhWorkspace &ws = mix->ws[mix->ws_next & 1];
   mix->ws_last = mix->ws_next & 1;
   mix->ws_next++;
   int rc = ph_workspace_ensure(ix, ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;
-  return ph_search_launch(ix, ws, a, stream);
+  // Large batches of independent queries descend in two launches: the upper layers in the
+  // caller's order, then the bottom layer with the queries sorted by where they landed (cell
+  // of the best candidate in the layer above), one contiguous eighth of that order per XCD.
+  // Same arithmetic per query, so the results are identical; neighbouring queries now share
+  // rows in L2 / the Infinity Cache.
+  const bool two = !a.order && !knn_mode && !out_stride && a.n_layers >= 2 && nq >= PH_TWO_LAUNCH_MIN &&
+                   ix->layers[a.n_layers - 1].n_nodes >= 65536 && !getenv("PHNSW_NO_LOCALITY");
+  if (!two) return ph_search_launch(ix, ws, a, stream);
+  g_two_launch_count++;
+  PhLayerHost &above = mix->layers[a.n_layers - 2];
+  rc = ph_layer_anchor_pos(ix->store, above);  // first use on a loaded index; no-op afterwards
+  if (!rc) rc = ph_workspace_order_ensure(ws, a.nq);
+  if (rc) return rc;
+  PhSearchArgs a1 = a;
+  a1.layer_lo = 0;
+  a1.layer_hi = a.n_layers - 1;
+  a1.out_hit = nullptr;
+  a1.out_key = ws.okey;
+  a1.key_pos = above.pos;
+  rc = ph_search_launch(ix, ws, a1, stream, true, false);
+  if (!rc) rc = ph_workspace_order_sort(ws, a.nq, stream);
+  if (rc) return rc;
+  a.layer_lo = a.n_layers - 1;
+  a.layer_hi = a.n_layers;
+  a.order = ws.oorder;
+  return ph_search_launch(ix, ws, a, stream, false, true);
 }
 
 extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq,
@@ -561,6 +611,18 @@ extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *que
   PH_HIP(hipSetDevice(ix->store->device));
   return ph_search_device(ix, queries_dev, ldq, qids_dev, nq, sp, upto_layers, exclude_dev, out_ids_dev, out_d_dev,
                           out_len_dev, out_stats_dev, status_dev, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int phnsw_debug_layer_pos(phnsw_index *ix, uint32_t lft, uint32_t *out_host) {
+  if (lft >= ix->layers.size() || !ix->layers[lft].pos) return PHNSW_E_INVALID;
+  PH_HIP(hipMemcpy(out_host, ix->layers[lft].pos, (size_t)ix->layers[lft].n_nodes * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int phnsw_debug_set_order(phnsw_index *ix, const uint32_t *order_dev, uint64_t n) {
+  ix->dbg_order = order_dev;
+  ix->dbg_order_n = n;
+  return 0;
 }
 
 extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {

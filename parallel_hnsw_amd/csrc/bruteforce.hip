@@ -219,6 +219,90 @@ extern "C" int phnsw_bruteforce_topk_device(const phnsw_store *s, const float *q
   return rc;
 }
 
+// ---- coarse cells for the locality schedule (phnsw_internal.h PhLayerHost::pos) ----
+__global__ void ph_gather_rows_f32_kernel(const float *rows, uint32_t ld, const uint32_t *ids, uint32_t stride,
+                                          uint32_t cnt, float *out) {
+  // one wave per row, float4 per lane
+  uint32_t r = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (r >= cnt) return;
+  const float4 *src = (const float4 *)(rows + (uint64_t)ids[(uint64_t)r * stride] * ld);
+  float4 *dst = (float4 *)(out + (uint64_t)r * ld);
+  for (uint32_t j = lane; j < ld / 4; j += 64) dst[j] = src[j];
+}
+
+// argmax of each score row (largest dot product = nearest for the dot-product metrics)
+__global__ __launch_bounds__(64) void ph_argmax_rows_kernel(const float *scores, uint64_t ldc, uint32_t na, uint32_t nq,
+                                                            uint32_t *out) {
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const float *row = scores + (uint64_t)q * ldc;
+    float best = -PH_FMAX;
+    uint32_t bi = 0;
+    for (uint32_t i = lane; i < na; i += 64) {
+      float v = row[i];
+      if (v > best) {
+        best = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      float ov = __shfl_xor(best, s);
+      uint32_t oi = __shfl_xor(bi, s);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) out[q] = bi;
+  }
+}
+
+// L.pos[node] = index of the nearest of A anchors (every (n/A)-th node of the layer).  No-op
+// for small layers, PQ stores and the L2 metric (the GEMM scores dot products).
+int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L) {
+  const uint32_t n = L.n_nodes;
+  if (L.pos || n < PH_ORDER_MIN || !s->rows || s->metric == PHNSW_METRIC_L2 || getenv("PHNSW_NO_LOCALITY")) return 0;
+  const uint32_t A = std::min<uint32_t>(4096u, n / 16u), stride = n / A, ld = s->ld;
+  const uint32_t QC = 65536;  // layer vectors per GEMM pass
+  float *anchors = nullptr, *qrows = nullptr, *scores = nullptr;
+  int rc = 0;
+  hipError_t e = hipMalloc(&anchors, (size_t)A * ld * 4);
+  if (e == hipSuccess) e = hipMalloc(&scores, (size_t)std::min(QC, n) * A * 4);
+  if (e == hipSuccess && !L.identity) e = hipMalloc(&qrows, (size_t)std::min(QC, n) * ld * 4);
+  if (e == hipSuccess) e = hipMalloc(&L.pos, (size_t)n * 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((A + 3) / 4), dim3(256), 0, 0, s->rows, ld, L.nodes, stride, A,
+                       anchors);
+    for (uint32_t first = 0; first < n; first += QC) {
+      const uint32_t cnt = std::min(QC, n - first);
+      const float *Q = s->rows + (uint64_t)first * ld;  // identity layer: node i is row i
+      if (!L.identity) {
+        hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((cnt + 3) / 4), dim3(256), 0, 0, s->rows, ld, L.nodes + first,
+                           1u, cnt, qrows);
+        Q = qrows;
+      }
+      dim3 grid((A + BF_TN - 1) / BF_TN, (cnt + BF_TM - 1) / BF_TM);
+      // the leading 256 dimensions are enough for a coarse cell (a hint, not a result)
+      hipLaunchKernelGGL(ph_gemm_nt_mfma_kernel, grid, dim3(256), 0, 0, Q, ld, cnt, anchors, ld, A,
+                         std::min<uint32_t>(ld, 256u), scores, (uint64_t)A);
+      hipLaunchKernelGGL(ph_argmax_rows_kernel, dim3(std::min<uint32_t>(cnt, 256u * 16u)), dim3(64), 0, 0, scores,
+                         (uint64_t)A, A, cnt, L.pos + first);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    rc = ph_hip_fail(e, "layer cells (anchor GEMM)", __FILE__, __LINE__);
+    if (L.pos) hipFree(L.pos);
+    L.pos = nullptr;
+  }
+  if (anchors) hipFree(anchors);
+  if (qrows) hipFree(qrows);
+  if (scores) hipFree(scores);
+  return rc;
+}
+
 // milliseconds the MFMA GEMM launches of the calling thread's last brute-force pass took
 extern "C" float phnsw_bruteforce_last_gemm_ms(void) { return g_bf_gemm_ms; }
 

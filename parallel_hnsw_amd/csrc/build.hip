@@ -530,7 +530,7 @@ static int ensure_row_dist(phnsw_index *ix, PhLayerHost &L) {
 // run the batched search for Stored queries and surface per-query failures
 static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32_t nq, const phnsw_search_params *sp,
                          uint32_t upto, const uint32_t *exclude_dev, uint32_t *out_ids, float *out_d,
-                         uint32_t *out_len, uint32_t out_stride, uint32_t *out_hit) {
+                         uint32_t *out_len, uint32_t out_stride, uint32_t *out_hit, const uint32_t *order = nullptr) {
   if (sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
     ph_set_error("build: search parameters out of range (number_of_candidates 1..1024, probe_depth >= 1)");
     return PHNSW_E_INVALID;
@@ -540,7 +540,7 @@ static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32
   uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
   for (int attempt = 0; attempt < 3; attempt++) {
     PH_TRY(ph_search_device(ix, nullptr, 0, qids_dev, nq, sp, upto, exclude_dev, out_ids, out_d, out_len, nullptr,
-                            status.p, ovf_cap, 0, 0, out_stride, out_hit));
+                            status.p, ovf_cap, 0, 0, out_stride, out_hit, 0.f, 0, 0.f, order));
     PH_HIP(hipDeviceSynchronize());
     std::vector<uint32_t> h(nq);
     PH_HIP(hipMemcpy(h.data(), status.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
@@ -750,6 +750,12 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
     delete P;
     return rc;
   }
+  if (!rc) rc = ph_layer_anchor_pos(ix->store, P->L);  // locality schedule of the build rounds (group.hip)
+  if (rc) {
+    ph_layer_free(P->L);
+    delete P;
+    return rc;
+  }
   P->K = K;
   ix->pending = P;
   if (ix->layers.empty()) {
@@ -793,8 +799,10 @@ static int layer_init_search_impl(phnsw_index *ix, const phnsw_build_params *bp,
   PH_TRY(res_d.alloc((size_t)count * K));
   PH_TRY(res_len.alloc(count));
   PH_TRY(bad.alloc(1));
+  const uint32_t *order = nullptr;
+  PH_TRY(ph_layer_range_order(P->L, first, count, &order));
   PH_TRY(search_stored(ix, P->L.nodes + first, count, &bp->initial_partition_search, 0, nullptr, res_ids.p, res_d.p,
-                       res_len.p, 0, nullptr));
+                       res_len.p, 0, nullptr, order));
   PH_HIP(hipMemsetAsync(bad.p, 0, 4, 0));
   hipLaunchKernelGGL(ph_init_from_search_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, P->L.nodes + first, count,
                      P->L.n_nodes, P->L.identity ? nullptr : P->L.vec2node, res_ids.p, res_d.p, res_len.p, K, out_ids,
@@ -911,8 +919,10 @@ static int link_search_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_pa
   }
   if (count == 0) return 0;
   PhLayerHost &L = ix->layers[lft];
+  const uint32_t *order = nullptr;
+  PH_TRY(ph_layer_range_order(L, first, count, &order));
   return search_stored(ix, L.nodes + first, count, sp, lft + 1, L.nodes + first, out_ids, out_d, out_len,
-                       (uint32_t)link_count, nullptr);
+                       (uint32_t)link_count, nullptr, order);
 }
 
 // link round, phase 2: all proposals -> rows (K5)  lib.rs:1118-1147
@@ -949,6 +959,16 @@ static int link_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_par
   PH_TRY(res_len.alloc(n));
   PH_TRY(link_search_impl(ix, lft, sp, link_count, 0, n, res_ids.p, res_d.p, res_len.p));
   return link_apply_impl(ix, lft, link_count, res_ids.p, res_d.p, res_len.p, out_added);
+}
+
+// position (locality schedule) of stored queries that are nodes of the layer
+__global__ void ph_query_pos_kernel(const uint32_t *qvec, uint32_t nq, const uint32_t *vec2node, const uint32_t *pos,
+                                    uint32_t n_nodes, uint32_t *out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  uint32_t v = qvec[i];
+  uint32_t nid = vec2node ? vec2node[v] : v;
+  out[i] = nid < n_nodes ? pos[nid] : PH_EMPTY32;
 }
 
 // the sample of stochastic_recall_at  lib.rs:1468-1483 (StdRng::seed_from_u64(42): the same
@@ -1004,7 +1024,17 @@ static int recall_hits_impl(phnsw_index *ix, uint32_t at, const phnsw_optimizati
   PH_TRY(d.alloc(nq));
   PH_TRY(len.alloc(nq));
   PH_TRY(hit.alloc(nq));
-  PH_TRY(search_stored(ix, q + first, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p));
+  DevBuf<uint32_t> okeys, order;
+  const PhLayerHost &L = ix->layers[at];
+  if (L.pos && nq >= PH_ORDER_MIN && !getenv("PHNSW_NO_LOCALITY")) {
+    PH_TRY(okeys.alloc(nq));
+    PH_TRY(order.alloc(nq));
+    hipLaunchKernelGGL(ph_query_pos_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, q + first, nq,
+                       L.identity ? nullptr : L.vec2node, L.pos, L.n_nodes, okeys.p);
+    PH_HIP(hipGetLastError());
+    PH_TRY(ph_order_by_keys_device(okeys.p, nq, order.p, 0));
+  }
+  PH_TRY(search_stored(ix, q + first, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p, order.p));
   std::vector<uint32_t> h(nq);
   PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
   uint64_t relevant = 0;
@@ -1076,9 +1106,11 @@ static int discover_hits_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_
   PH_TRY(len.alloc(count));
   PH_TRY(status.alloc(count));
   uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+  const uint32_t *order = nullptr;
+  PH_TRY(ph_layer_range_order(L, first, count, &order));
   for (int attempt = 0; attempt < 3; attempt++) {
     PH_TRY(ph_search_device(ix, nullptr, 0, L.nodes + first, count, sp, lft + 1, nullptr, ids.p, d.p, len.p, nullptr,
-                            status.p, ovf_cap, 0, 0, 1, hit_dev, 0.f, 0, 1e-5f));
+                            status.p, ovf_cap, 0, 0, 1, hit_dev, 0.f, 0, 1e-5f, order));
     PH_HIP(hipDeviceSynchronize());
     std::vector<uint32_t> hs(count);
     PH_HIP(hipMemcpy(hs.data(), status.p, (size_t)count * 4, hipMemcpyDeviceToHost));
@@ -1173,6 +1205,20 @@ static int extend_layer_impl(phnsw_index *ix, uint32_t lft, std::vector<uint32_t
     if (e != hipSuccess) {
       ph_layer_free(NL);
       return ph_hip_fail(e, "extend_layer upload", __FILE__, __LINE__);
+    }
+  }
+  if (L.pos) {  // keep the locality order: old nodes keep their rank, new nodes go last
+    std::vector<uint32_t> op(n_old), np(n_new, PH_EMPTY32);
+    PH_HIP(hipMemcpy(op.data(), L.pos, (size_t)n_old * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_old; i++) np[old_map[i]] = op[i];
+    uint32_t next = n_old;
+    for (uint32_t i = 0; i < n_new; i++)
+      if (np[i] == PH_EMPTY32) np[i] = next++;
+    hipError_t e = hipMalloc(&NL.pos, (size_t)n_new * 4);
+    if (e == hipSuccess) e = hipMemcpy(NL.pos, np.data(), (size_t)n_new * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      ph_layer_free(NL);
+      return ph_hip_fail(e, "extend_layer positions", __FILE__, __LINE__);
     }
   }
   ph_layer_free(L);

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include "phnsw_internal.h"
+
 #include "phnsw_device.h"
 
 __global__ void ph_group_keys_kernel(const uint32_t *init_ids, const float *init_d, const uint32_t *init_len,
@@ -64,4 +66,80 @@ int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const 
   if (vals_in) hipFree(vals_in);
   if (tmp) hipFree(tmp);
   return rc;
+}
+
+// ---- locality schedule (a scheduling hint, never part of a result) ----
+// Every large layer carries pos[node] = the node's coarse cell: its exact nearest anchor, the
+// anchors being a strided sample of the layer (bruteforce.hip, one MFMA GEMM pass).  The search
+// kernel walks a query list sorted by cell, one contiguous eighth per XCD, so that the rows
+// one L2 / the Infinity Cache serve together belong to neighbouring queries (search.hip).
+
+__global__ void ph_iota_kernel(uint32_t *v, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// order_out [n] = argsort (stable) of 32-bit keys; used to turn per-query positions into the
+// processing order of one launch
+int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st) {
+  uint32_t *keys_out = nullptr, *vals_in = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = 0;
+  hipError_t e = hipMalloc(&keys_out, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(&vals_in, (size_t)n * 4);
+  if (e == hipSuccess)
+    e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, vals_in, order_out, (int)n, 0, 32, st);
+  if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ph_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vals_in, n);
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, vals_in, order_out, (int)n, 0, 32, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (e != hipSuccess) rc = ph_hip_fail(e, "query order (radix sort)", __FILE__, __LINE__);
+  if (keys_out) hipFree(keys_out);
+  if (vals_in) hipFree(vals_in);
+  if (tmp) hipFree(tmp);
+  return rc;
+}
+
+// ---- per-workspace argsort of the queries' locality keys, fully asynchronous on `stream`
+// (buffers grow only when a larger batch arrives)
+void ph_workspace_order_free(PhWorkspace &ws) {
+  if (ws.okey) hipFree(ws.okey);
+  if (ws.okey_sorted) hipFree(ws.okey_sorted);
+  if (ws.oiota) hipFree(ws.oiota);
+  if (ws.oorder) hipFree(ws.oorder);
+  if (ws.sort_tmp) hipFree(ws.sort_tmp);
+  ws.okey = ws.okey_sorted = ws.oiota = ws.oorder = nullptr;
+  ws.sort_tmp = nullptr;
+  ws.sort_tmp_bytes = 0;
+  ws.order_cap = 0;
+}
+
+int ph_workspace_order_ensure(PhWorkspace &ws, uint32_t nq) {
+  if (ws.order_cap >= nq) return 0;
+  ph_workspace_order_free(ws);
+  uint32_t cap = std::max<uint32_t>(nq, 65536u);
+  PH_HIP(hipMalloc(&ws.okey, (size_t)cap * 4));
+  PH_HIP(hipMalloc(&ws.okey_sorted, (size_t)cap * 4));
+  PH_HIP(hipMalloc(&ws.oiota, (size_t)cap * 4));
+  PH_HIP(hipMalloc(&ws.oorder, (size_t)cap * 4));
+  size_t bytes = 0;
+  PH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ws.okey, ws.okey_sorted, ws.oiota, ws.oorder, (int)cap, 0, 32,
+                                            (hipStream_t)0));
+  ws.sort_tmp_bytes = std::max<size_t>(bytes, 16);
+  PH_HIP(hipMalloc(&ws.sort_tmp, ws.sort_tmp_bytes));
+  hipLaunchKernelGGL(ph_iota_kernel, dim3((cap + 255) / 256), dim3(256), 0, 0, ws.oiota, cap);
+  PH_HIP(hipDeviceSynchronize());
+  ws.order_cap = cap;
+  return 0;
+}
+
+// ws.oorder[0..nq) = argsort(ws.okey[0..nq))
+int ph_workspace_order_sort(PhWorkspace &ws, uint32_t nq, hipStream_t stream) {
+  size_t bytes = ws.sort_tmp_bytes;
+  PH_HIP(hipcub::DeviceRadixSort::SortPairs(ws.sort_tmp, bytes, ws.okey, ws.okey_sorted, ws.oiota, ws.oorder, (int)nq, 0,
+                                            32, stream));
+  return 0;
 }

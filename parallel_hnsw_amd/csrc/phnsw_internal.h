@@ -42,6 +42,11 @@ struct PhLayerHost {
   bool identity = false;
   uint32_t *recall_q = nullptr;  // cached stochastic_recall_at sample (build.hip), recall_n entries
   uint32_t recall_n = 0;
+  // locality schedule (group.hip): pos[node] = the node's coarse cell (its exact nearest
+  // anchor, anchors = a strided sample of the layer); ord = argsort(pos[ord_first .. +ord_count)), cached
+  uint32_t *pos = nullptr;
+  uint32_t *ord = nullptr;
+  uint32_t ord_first = 0, ord_count = 0;
 };
 
 // what a distance evaluation needs: the f32 store, or -- for a product-quantised store --
@@ -82,6 +87,11 @@ struct PhWorkspace {
   uint32_t *counter = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  // two-launch descents: per-query locality keys, their argsort, radix-sort scratch
+  uint32_t *okey = nullptr, *okey_sorted = nullptr, *oiota = nullptr, *oorder = nullptr;
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  uint32_t order_cap = 0;
 };
 
 struct PhPendingLayer;
@@ -96,6 +106,8 @@ struct phnsw_index {
   PhWorkspace ws[2];
   uint32_t ws_next = 0, ws_last = 0;
   float last_kernel_ms = 0.f;
+  const uint32_t *dbg_order = nullptr;  // experiment hook
+  uint64_t dbg_order_n = 0;
 };
 
 // ---- kernel argument block for the batched greedy search ----
@@ -127,6 +139,11 @@ struct PhSearchArgs {
   uint32_t cap_max;     // threshold_nn: largest queue capacity the launch must support (0 = ef)
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
+  uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip
+  uint32_t *out_key;            // nullable: locality key of each query after layer_hi - 1
+  const uint32_t *key_pos;      // nullable: pos[] of layer layer_hi - 1
+  const uint32_t *order;  // nullable: processing order (a permutation of 0..nq-1), see search.hip
+  uint32_t seg;           // order != nullptr: positions per XCD segment
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
 };
 
@@ -139,10 +156,20 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride = 0,
                      uint32_t *out_hit = nullptr, float threshold = 0.f, uint32_t first_node = 0,
-                     float hit_eps = 0.f);
+                     float hit_eps = 0.f, const uint32_t *order = nullptr);
+// locality schedule helpers (group.hip / api.hip)
+#define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
+int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip
+int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st);
+int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const uint32_t **out);
 
 // launchers (search.hip)
-int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream);
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream,
+                     bool mark_begin = true, bool mark_end = true);
+int ph_workspace_order_ensure(PhWorkspace &ws, uint32_t nq);                          // group.hip
+int ph_workspace_order_sort(PhWorkspace &ws, uint32_t nq, hipStream_t stream);        // group.hip
+void ph_workspace_order_free(PhWorkspace &ws);                                        // group.hip
+#define PH_TWO_LAUNCH_MIN 32768u  // batches at least this large descend in two launches
 int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uint32_t ovf_cap);
 void ph_workspace_free(PhWorkspace &ws);
 uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds);

@@ -53,13 +53,48 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
   uint2 *ovf = a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
 
+  // locality schedule: with an `order` the query list is cut into 8 consecutive segments, one
+  // per XCD, so that the queries one L2 serves together are neighbours in `order`; a wave
+  // whose segment is exhausted moves on to the next one (no idle tail)
+  uint32_t seg_cur = 0, seg_done = 0;
+  if (a.order) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    seg_cur = (xcc & 15u) & 7u;
+  }
+
   for (;;) {
     uint32_t q = 0;
-    if (lane == 0) q = atomicAdd(a.counter, 1u);
-    q = rfl32(q);
-    if (q >= a.nq) break;
+    if (!a.order) {
+      if (lane == 0) q = atomicAdd(a.counter, 1u);
+      q = rfl32(q);
+      if (q >= a.nq) break;
+    } else {
+      for (;;) {
+        uint32_t p = 0;
+        if (lane == 0) p = atomicAdd(a.counter + seg_cur * 16u, 1u);
+        p = rfl32(p);
+        const uint32_t base = seg_cur * a.seg;
+        const uint32_t len = base >= a.nq ? 0u : min(a.seg, a.nq - base);
+        if (p < len) {
+          q = a.order[base + p];
+          break;
+        }
+        seg_cur = (seg_cur + 1u) & 7u;
+        if (++seg_done == 8u) {
+          q = PH_EMPTY32;
+          break;
+        }
+      }
+      if (q == PH_EMPTY32) break;
+    }
 
     const uint32_t last_layer = a.n_layers - 1;
+    // a descent may run as two launches (upper layers; then the bottom layer with the queries
+    // re-ordered by where they landed): layers [layer_lo, layer_hi) of this launch, the running
+    // candidates parked in the output rows in between
+    const uint32_t layer_hi = a.layer_hi ? a.layer_hi : a.n_layers;
+    if (a.layer_lo && a.status[q] != ST_OK) continue;  // failed in the first launch: keep its status
     const uint32_t qnode = a.first_node + q;  // knn modes: the query is a node of the bottom layer
     uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[qnode] : (a.qids ? a.qids[q] : 0u);
     Dist dist;
@@ -72,7 +107,21 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
 
-    if (!a.knn_mode) {
+    if (a.layer_lo) {
+      clen = a.out_len[q];
+#pragma unroll
+      for (int c = 0; c < CAPC; c++) {
+        uint32_t i = lane + 64u * c;
+        if (i < clen) {
+          Cid[i] = a.out_ids[(uint64_t)q * a.ef + i];
+          Cd[i] = a.out_d[(uint64_t)q * a.ef + i];
+        }
+      }
+      if (a.out_stats) {
+        n_dist = a.out_stats[2 * (uint64_t)q];
+        n_hops = a.out_stats[2 * (uint64_t)q + 1];
+      }
+    } else if (!a.knn_mode) {
       // entry_vector + distance_from_entry  search.rs:101-111
       uint32_t entry = a.layers[0].nodes[0];
       float d0 = dist.batch(a.dist, 1ull, entry, lane);
@@ -86,7 +135,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
     }
     __syncthreads();
 
-    for (uint32_t li = a.knn_mode ? last_layer : 0; li < a.n_layers && err == ST_OK; li++) {
+    for (uint32_t li = a.knn_mode ? last_layer : a.layer_lo; li < layer_hi && err == ST_OK; li++) {
       const PhLayerDev L = a.layers[li];
       const bool identity = L.vec2node == nullptr;
       // ---- closest_vectors: VectorId -> NodeId, queue = new(cap); merge_pairs  lib.rs:258-266
@@ -469,6 +518,16 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       uint64_t hm = __ballot(hit);
       if (lane == 0) a.out_hit[q] = hm ? 1u : 0u;
     }
+    if (a.out_key && lane == 0) {
+      // where the query landed: the cell (or node) of its best candidate in the last layer done
+      uint32_t key = PH_EMPTY32;
+      if (clen) {
+        const PhLayerDev KL = a.layers[layer_hi - 1];
+        uint32_t nid = KL.vec2node ? KL.vec2node[Cid[0]] : Cid[0];
+        if (nid < KL.n_nodes) key = a.key_pos ? a.key_pos[nid] : nid;
+      }
+      a.out_key[q] = key;
+    }
     if (lane == 0) {
       a.out_len[q] = clen;
       a.status[q] = err;
@@ -523,8 +582,11 @@ uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds) != hipSuccess || per_cu <= 0)
     per_cu = 1;
   int cap = 16;
-  if (const char *e = getenv("PHNSW_WAVES_PER_CU")) cap = atoi(e) > 0 ? atoi(e) : cap;
   per_cu = std::min(per_cu, cap);
+  if (const char *e = getenv("PHNSW_WAVES_PER_CU")) {  // tuning knob: trusts the caller over the occupancy query
+    if (atoi(e) > 0) per_cu = atoi(e);
+    if (getenv("PHNSW_VERBOSE")) fprintf(stderr, "[phnsw] search grid: %d waves per CU (forced), lds %zu\n", per_cu, lds);
+  }
   return (uint32_t)(per_cu * prop.multiProcessorCount);
 }
 
@@ -534,6 +596,7 @@ void ph_workspace_free(PhWorkspace &ws) {
   if (ws.counter) hipFree(ws.counter);
   if (ws.ev0) hipEventDestroy(ws.ev0);
   if (ws.ev1) hipEventDestroy(ws.ev1);
+  ph_workspace_order_free(ws);
   ws = PhWorkspace();
 }
 
@@ -548,7 +611,7 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
     return PHNSW_E_UNSUPPORTED;
   }
   if (!ws.counter) {
-    PH_HIP(hipMalloc(&ws.counter, 256));
+    PH_HIP(hipMalloc(&ws.counter, 512));  // 8 work counters, 64 B apart
     PH_HIP(hipEventCreate(&ws.ev0));
     PH_HIP(hipEventCreate(&ws.ev1));
   }
@@ -575,7 +638,8 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   return 0;
 }
 
-int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream) {
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_begin,
+                     bool mark_end) {
   const bool pq = ix->store->codes != nullptr;
   const size_t pq_lds = ph_pq_lds_bytes(ix->store);
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
@@ -594,12 +658,15 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   if (grid == 0) return 0;
   // launches share the per-wave workspace (visited bitmaps, spill lists): order a launch on
   // another stream behind the previous one
-  if (ws.timed) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
-  PH_HIP(hipMemsetAsync(ws.counter, 0, 4, stream));
-  PH_HIP(hipEventRecord(ws.ev0, stream));
+  if (ws.timed && mark_begin) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
+  PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));
+  a.seg = a.order ? (a.nq + 7u) / 8u : 0u;
+  if (mark_begin) PH_HIP(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc, pq_lds), stream, a);
   PH_HIP(hipGetLastError());
-  PH_HIP(hipEventRecord(ws.ev1, stream));
-  ws.timed = true;
+  if (mark_end) {
+    PH_HIP(hipEventRecord(ws.ev1, stream));
+    ws.timed = true;
+  }
   return 0;
 }

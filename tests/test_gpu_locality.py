@@ -1,0 +1,92 @@
+"""The locality schedule (XCD-segmented, cell-ordered query lists; two-launch descents for large
+batches) is a scheduling hint: every result must be bit-identical to the plain schedule and to
+the oracle.  Covers the build rounds (ordered node ranges) and large search batches."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parallel_hnsw_amd as ph
+from parallel_hnsw_amd._lib import lib
+
+pytestmark = pytest.mark.gpu
+
+N, DIM, NQ = 70_000, 64, 40_000
+
+
+def two_launch_count():
+    f = lib().phnsw_debug_two_launch_count
+    f.restype = C.c_uint64
+    return f()
+
+
+class plain_schedule:
+    def __enter__(self):
+        os.environ["PHNSW_NO_LOCALITY"] = "1"
+
+    def __exit__(self, *a):
+        del os.environ["PHNSW_NO_LOCALITY"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    store = ph.VectorStore.clustered(N, DIM, seed=42, n_clusters=70)
+    bp = ph.BuildParameters(max_link_rounds=1)
+    h = ph.Hnsw.generate(store, np.arange(N, dtype=np.uint64), bp)
+    return store, h, bp
+
+
+def layers_equal(a, b):
+    assert a.layer_count() == b.layer_count()
+    for x, y in zip(a.layers, b.layers):
+        np.testing.assert_array_equal(x.nodes, y.nodes)
+        np.testing.assert_array_equal(x.neighbors, y.neighbors)
+
+
+def test_build_is_schedule_independent(built):
+    store, h, bp = built
+    with plain_schedule():
+        h2 = ph.Hnsw.generate(store, np.arange(N, dtype=np.uint64), bp)
+    layers_equal(h, h2)
+
+
+def test_large_batch_two_launch_equals_single_launch_and_oracle(built):
+    store, h, _ = built
+    q = ph.VectorStore.clustered(NQ, DIM, seed=42, first=2 ** 33, n_clusters=70).read()
+    sp = ph.SearchParameters(32, 20, 2)  # upper_layer_candidate_count != number_of_candidates on purpose
+    before = two_launch_count()
+    two = h.search_batch(queries=q, sp=sp, stats=True)
+    assert two_launch_count() == before + 1
+    with plain_schedule():
+        one = h.search_batch(queries=q, sp=sp, stats=True)
+    assert two_launch_count() == before + 1
+    for a, b in zip(two, one):
+        np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    # oracle on the same graph, a slice of the batch
+    ix = oracle.Index(store.read(), dim=DIM, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_BLOCKED64)
+    for l in h.layers:
+        ix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    m = 3000
+    ci, cd, cl, cs = ix.search(queries=q[:m], sp=(32, 20, 2), stats=True)
+    np.testing.assert_array_equal(two[0][:m], ci)
+    np.testing.assert_array_equal(two[1][:m].view(np.uint32), cd.view(np.uint32))
+    np.testing.assert_array_equal(two[2][:m], cl)
+    np.testing.assert_array_equal(two[3][:m], cs)
+
+
+def test_large_stored_batch_with_exclude(built):
+    store, h, _ = built
+    rng = np.random.default_rng(5)
+    qids = rng.integers(0, N, NQ).astype(np.uint64)
+    sp = ph.SearchParameters(16, 16, 2)
+    before = two_launch_count()
+    two = h.search_batch(qids=qids, exclude=qids, sp=sp, stats=True)
+    assert two_launch_count() == before + 1
+    with plain_schedule():
+        one = h.search_batch(qids=qids, exclude=qids, sp=sp, stats=True)
+    np.testing.assert_array_equal(two[0], one[0])
+    np.testing.assert_array_equal(two[1].view(np.uint32), one[1].view(np.uint32))
+    np.testing.assert_array_equal(two[2], one[2])
+    np.testing.assert_array_equal(two[3], one[3])
