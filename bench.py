@@ -407,15 +407,18 @@ def main():
             "recall_target_met": res["recall_target_met"],
             "build_vectors_per_sec": round(args.n / res["build_s"], 1),
             "build_mode": res["build_mode"],
+            "queries_per_step_per_gpu": args.nq, "argv": " ".join(sys.argv[1:]),
             "distance_evals_per_query": round(res["n_dist_per_query"], 1),
             "hops_per_query": round(res["n_hops_per_query"], 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "ph_search_kernel", "kernel_ms": round(res["kernel_ms"], 4),
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
-                         # batches >= 32768 queries descend in two dispatches of the same kernel (upper
-                         # layers; bottom layer in locality order): kernel_ms spans both (HIP events)
-                         "dispatches_per_launch": 2 if args.nq >= 32768 else 1,
+                         # batches >= 32768 queries descend in several dispatches of the same kernel (small top
+                         # layers; then each large layer in locality order): kernel_ms spans all (HIP events)
+                         "dispatches_per_launch": (1 + sum(1 for l in range(1, index.layer_count())
+                                                          if index._layer(l).node_count() >= 32768))
+                         if args.nq >= 32768 else 1,
                          "note": "achieved = algorithmic bytes / time; it can exceed the HBM peak because "
                                  "neighbouring queries are scheduled together and share rows in L2 / the Infinity "
                                  "Cache (traffic = measured HBM bytes)",

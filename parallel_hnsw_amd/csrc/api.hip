@@ -255,6 +255,7 @@ extern "C" void phnsw_store_destroy(phnsw_store *s) {
   if (s->owns_rows && s->rows) hipFree(s->rows);
   if (s->codes) hipFree(s->codes);
   if (s->codebook) hipFree(s->codebook);
+  ph_store_anchors_free(s);
   delete s;
 }
 
@@ -567,32 +568,41 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   mix->ws_next++;
   int rc = ph_workspace_ensure(ix, ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;
-  // Large batches of independent queries descend in two launches: the upper layers in the
-  // caller's order, then the bottom layer with the queries sorted by where they landed (cell
-  // of the best candidate in the layer above), one contiguous eighth of that order per XCD.
-  // Same arithmetic per query, so the results are identical; neighbouring queries now share
-  // rows in L2 / the Infinity Cache.
-  const bool two = !a.order && !knn_mode && !out_stride && a.n_layers >= 2 && nq >= PH_TWO_LAUNCH_MIN &&
-                   ix->layers[a.n_layers - 1].n_nodes >= 65536 && !getenv("PHNSW_NO_LOCALITY");
-  if (!two) return ph_search_launch(ix, ws, a, stream);
+  // Large batches of independent queries descend in several launches: the small top layers in
+  // the caller's order, then every large layer in a launch of its own with the queries sorted by
+  // where they landed in the layer above (cell of the best candidate), one contiguous eighth of
+  // that order per XCD.  Same arithmetic per query, so the results are identical; neighbouring
+  // queries now share rows in L2 / the Infinity Cache.  Between launches the running candidates
+  // are parked in the output rows.
+  uint32_t first_big = a.n_layers;
+  for (uint32_t l = 1; l < a.n_layers; l++)
+    if (ix->layers[l].n_nodes >= PH_SPLIT_MIN) {
+      first_big = l;
+      break;
+    }
+  const bool split = !a.order && !knn_mode && !out_stride && first_big < a.n_layers && nq >= PH_TWO_LAUNCH_MIN &&
+                     !getenv("PHNSW_NO_LOCALITY");
+  if (!split) return ph_search_launch(ix, ws, a, stream);
   g_two_launch_count++;
-  PhLayerHost &above = mix->layers[a.n_layers - 2];
-  rc = ph_layer_anchor_pos(ix->store, above);  // first use on a loaded index; no-op afterwards
-  if (!rc) rc = ph_workspace_order_ensure(ws, a.nq);
+  rc = ph_workspace_order_ensure(ws, a.nq);
+  for (uint32_t l = first_big; l < a.n_layers && !rc; l++)
+    rc = ph_layer_anchor_pos(ix->store, mix->layers[l - 1]);  // first use on a loaded index; no-op afterwards
   if (rc) return rc;
-  PhSearchArgs a1 = a;
-  a1.layer_lo = 0;
-  a1.layer_hi = a.n_layers - 1;
-  a1.out_hit = nullptr;
-  a1.out_key = ws.okey;
-  a1.key_pos = above.pos;
-  rc = ph_search_launch(ix, ws, a1, stream, true, false);
-  if (!rc) rc = ph_workspace_order_sort(ws, a.nq, stream);
-  if (rc) return rc;
-  a.layer_lo = a.n_layers - 1;
-  a.layer_hi = a.n_layers;
-  a.order = ws.oorder;
-  return ph_search_launch(ix, ws, a, stream, false, true);
+  uint32_t *const out_hit_final = a.out_hit;
+  for (uint32_t lo = 0, hi = first_big; lo < a.n_layers; lo = hi, hi = hi + 1) {
+    PhSearchArgs p = a;
+    const bool last = hi == a.n_layers;
+    p.layer_lo = lo;
+    p.layer_hi = hi;
+    p.order = lo ? ws.oorder : nullptr;
+    p.out_hit = last ? out_hit_final : nullptr;
+    p.out_key = last ? nullptr : ws.okey;
+    p.key_pos = last ? nullptr : ix->layers[hi - 1].pos;
+    rc = ph_search_launch(ix, ws, p, stream, lo == 0, last);
+    if (!rc && !last) rc = ph_workspace_order_sort(ws, a.nq, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq,

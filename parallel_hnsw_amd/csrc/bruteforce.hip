@@ -258,22 +258,129 @@ __global__ __launch_bounds__(64) void ph_argmax_rows_kernel(const float *scores,
   }
 }
 
-// L.pos[node] = index of the nearest of A anchors (every (n/A)-th node of the layer).  No-op
-// for small layers, PQ stores and the L2 metric (the GEMM scores dot products).
-int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L) {
-  const uint32_t n = L.n_nodes;
-  if (L.pos || n < PH_ORDER_MIN || !s->rows || s->metric == PHNSW_METRIC_L2 || getenv("PHNSW_NO_LOCALITY")) return 0;
-  const uint32_t A = std::min<uint32_t>(4096u, n / 16u), stride = n / A, ld = s->ld;
-  const uint32_t QC = 65536;  // layer vectors per GEMM pass
-  float *anchors = nullptr, *qrows = nullptr, *scores = nullptr;
-  int rc = 0;
+// Greedy nearest-neighbour chain over the anchors: rank[a] = position of anchor a on a path
+// that always moves to the most similar anchor not yet visited, so cells that are close in
+// space get close ranks.  One 1024-thread block; scores is the A x A anchor Gram matrix.
+__global__ __launch_bounds__(1024) void ph_anchor_chain_kernel(const float *scores, uint32_t A, uint32_t *rank) {
+  extern __shared__ uint32_t sm[];
+  uint32_t *seen = sm;                 // [A] flags
+  float *wbest = (float *)(sm + A);    // [16]
+  uint32_t *widx = sm + A + 16;        // [16]
+  __shared__ uint32_t cur_s;
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (uint32_t i = t; i < A; i += 1024) seen[i] = 0;
+  if (t == 0) {
+    cur_s = 0;
+    seen[0] = 1;
+    rank[0] = 0;
+  }
+  __syncthreads();
+  for (uint32_t step = 1; step < A; step++) {
+    const uint32_t cur = cur_s;
+    const float *row = scores + (uint64_t)cur * A;
+    float best = -PH_FMAX;
+    uint32_t bi = PH_EMPTY32;
+    for (uint32_t j = t; j < A; j += 1024)
+      if (!seen[j]) {
+        float v = row[j];
+        if (bi == PH_EMPTY32 || v > best) {
+          best = v;
+          bi = j;
+        }
+      }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      float ov = __shfl_xor(best, sft);
+      uint32_t oi = __shfl_xor(bi, sft);
+      if (oi != PH_EMPTY32 && (bi == PH_EMPTY32 || ov > best || (ov == best && oi < bi))) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      wbest[w] = best;
+      widx[w] = bi;
+    }
+    __syncthreads();
+    if (t == 0) {
+      float b = -PH_FMAX;
+      uint32_t i = PH_EMPTY32;
+      for (int k = 0; k < 16; k++)
+        if (widx[k] != PH_EMPTY32 && (i == PH_EMPTY32 || wbest[k] > b || (wbest[k] == b && widx[k] < i))) {
+          b = wbest[k];
+          i = widx[k];
+        }
+      cur_s = i;
+      seen[i] = 1;
+      rank[i] = step;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void ph_rank_of_cell_kernel(uint32_t *pos, uint32_t n, const uint32_t *rank) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] = rank[pos[i]];
+}
+
+// The store's coarse cells: A anchors (every (n/A)-th row) and their chain ranks, made once.
+static int ph_store_anchors(phnsw_store *s) {
+  if (s->anchors) return 0;
+  const uint32_t A = (uint32_t)std::min<uint64_t>(4096u, std::max<uint64_t>(s->n / 16u, 1u)), ld = s->ld;
+  const uint64_t stride = s->n / A;
+  float *anchors = nullptr, *gram = nullptr;
+  uint32_t *rank = nullptr, *ids = nullptr;
+  std::vector<uint32_t> h(A);
+  for (uint32_t a = 0; a < A; a++) h[a] = (uint32_t)(a * stride);
   hipError_t e = hipMalloc(&anchors, (size_t)A * ld * 4);
-  if (e == hipSuccess) e = hipMalloc(&scores, (size_t)std::min(QC, n) * A * 4);
+  if (e == hipSuccess) e = hipMalloc(&gram, (size_t)A * A * 4);
+  if (e == hipSuccess) e = hipMalloc(&rank, (size_t)A * 4);
+  if (e == hipSuccess) e = hipMalloc(&ids, (size_t)A * 4);
+  if (e == hipSuccess) e = hipMemcpy(ids, h.data(), (size_t)A * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((A + 3) / 4), dim3(256), 0, 0, s->rows, ld, ids, 1u, A, anchors);
+    dim3 grid((A + BF_TN - 1) / BF_TN, (A + BF_TM - 1) / BF_TM);
+    hipLaunchKernelGGL(ph_gemm_nt_mfma_kernel, grid, dim3(256), 0, 0, anchors, ld, A, anchors, ld, A, ld, gram, (uint64_t)A);
+    hipLaunchKernelGGL(ph_anchor_chain_kernel, dim3(1), dim3(1024), (A + 32) * 4, 0, gram, A, rank);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (gram) hipFree(gram);
+  if (ids) hipFree(ids);
+  if (e != hipSuccess) {
+    if (anchors) hipFree(anchors);
+    if (rank) hipFree(rank);
+    return ph_hip_fail(e, "store cells (anchors)", __FILE__, __LINE__);
+  }
+  s->anchors = anchors;
+  s->anchor_rank = rank;
+  s->n_anchors = A;
+  return 0;
+}
+
+void ph_store_anchors_free(phnsw_store *s) {
+  if (s->anchors) hipFree(s->anchors);
+  if (s->anchor_rank) hipFree(s->anchor_rank);
+  s->anchors = nullptr;
+  s->anchor_rank = nullptr;
+}
+
+// L.pos[node] = chain rank of the node's nearest anchor.  No-op for small layers, PQ stores and
+// the L2 metric (the GEMM scores dot products).
+int ph_layer_anchor_pos(const phnsw_store *cs, PhLayerHost &L) {
+  phnsw_store *s = const_cast<phnsw_store *>(cs);
+  const uint32_t n = L.n_nodes;
+  if (L.pos || n < PH_POS_MIN || !s->rows || s->n < 65536 || s->metric == PHNSW_METRIC_L2 || getenv("PHNSW_NO_LOCALITY"))
+    return 0;
+  int rc = ph_store_anchors(s);
+  if (rc) return rc;
+  const uint32_t A = s->n_anchors, ld = s->ld;
+  const uint32_t QC = 65536;  // layer vectors per GEMM pass
+  float *qrows = nullptr, *scores = nullptr;
+  hipError_t e = hipMalloc(&scores, (size_t)std::min(QC, n) * A * 4);
   if (e == hipSuccess && !L.identity) e = hipMalloc(&qrows, (size_t)std::min(QC, n) * ld * 4);
   if (e == hipSuccess) e = hipMalloc(&L.pos, (size_t)n * 4);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((A + 3) / 4), dim3(256), 0, 0, s->rows, ld, L.nodes, stride, A,
-                       anchors);
     for (uint32_t first = 0; first < n; first += QC) {
       const uint32_t cnt = std::min(QC, n - first);
       const float *Q = s->rows + (uint64_t)first * ld;  // identity layer: node i is row i
@@ -284,11 +391,12 @@ int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L) {
       }
       dim3 grid((A + BF_TN - 1) / BF_TN, (cnt + BF_TM - 1) / BF_TM);
       // the leading 256 dimensions are enough for a coarse cell (a hint, not a result)
-      hipLaunchKernelGGL(ph_gemm_nt_mfma_kernel, grid, dim3(256), 0, 0, Q, ld, cnt, anchors, ld, A,
+      hipLaunchKernelGGL(ph_gemm_nt_mfma_kernel, grid, dim3(256), 0, 0, Q, ld, cnt, s->anchors, ld, A,
                          std::min<uint32_t>(ld, 256u), scores, (uint64_t)A);
       hipLaunchKernelGGL(ph_argmax_rows_kernel, dim3(std::min<uint32_t>(cnt, 256u * 16u)), dim3(64), 0, 0, scores,
                          (uint64_t)A, A, cnt, L.pos + first);
     }
+    hipLaunchKernelGGL(ph_rank_of_cell_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.pos, n, s->anchor_rank);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
@@ -297,7 +405,6 @@ int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L) {
     if (L.pos) hipFree(L.pos);
     L.pos = nullptr;
   }
-  if (anchors) hipFree(anchors);
   if (qrows) hipFree(qrows);
   if (scores) hipFree(scores);
   return rc;

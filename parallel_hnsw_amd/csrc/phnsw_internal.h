@@ -42,8 +42,8 @@ struct PhLayerHost {
   bool identity = false;
   uint32_t *recall_q = nullptr;  // cached stochastic_recall_at sample (build.hip), recall_n entries
   uint32_t recall_n = 0;
-  // locality schedule (group.hip): pos[node] = the node's coarse cell (its exact nearest
-  // anchor, anchors = a strided sample of the layer); ord = argsort(pos[ord_first .. +ord_count)), cached
+  // locality schedule: pos[node] = the node's coarse cell (chain rank of its nearest anchor,
+  // anchors = a strided sample of the store; bruteforce.hip); ord = argsort(pos[ord_first .. +ord_count)), cached
   uint32_t *pos = nullptr;
   uint32_t *ord = nullptr;
   uint32_t ord_first = 0, ord_count = 0;
@@ -70,6 +70,10 @@ struct phnsw_store {
   float *codebook = nullptr;
   uint32_t pq_m = 0, pq_ksub = 0, pq_dsub = 0;
   uint32_t pq_table_f16 = 0;
+  // coarse cells of the locality schedule (bruteforce.hip): anchor rows + their chain ranks
+  float *anchors = nullptr;
+  uint32_t *anchor_rank = nullptr;
+  uint32_t n_anchors = 0;
   bool owns_rows = true;
   uint64_t n = 0;
   uint32_t dim = 0, ld = 0;
@@ -159,7 +163,10 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      float hit_eps = 0.f, const uint32_t *order = nullptr);
 // locality schedule helpers (group.hip / api.hip)
 #define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
+#define PH_POS_MIN 1024u     // smaller layers carry no cells (their node id is the key)
+#define PH_SPLIT_MIN 32768u  // a layer at least this large gets a launch of its own in a split descent
 int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip
+void ph_store_anchors_free(phnsw_store *s);
 int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st);
 int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const uint32_t **out);
 

@@ -13,7 +13,7 @@ from parallel_hnsw_amd._lib import lib
 
 pytestmark = pytest.mark.gpu
 
-N, DIM, NQ = 70_000, 64, 40_000
+N, DIM, NQ = 400_000, 32, 40_000  # layers [.., 33333, 400000]: two layers large enough for a launch of their own
 
 
 def two_launch_count():
@@ -32,7 +32,7 @@ class plain_schedule:
 
 @pytest.fixture(scope="module")
 def built():
-    store = ph.VectorStore.clustered(N, DIM, seed=42, n_clusters=70)
+    store = ph.VectorStore.clustered(N, DIM, seed=42, n_clusters=400)
     bp = ph.BuildParameters(max_link_rounds=1)
     h = ph.Hnsw.generate(store, np.arange(N, dtype=np.uint64), bp)
     return store, h, bp
@@ -54,7 +54,7 @@ def test_build_is_schedule_independent(built):
 
 def test_large_batch_two_launch_equals_single_launch_and_oracle(built):
     store, h, _ = built
-    q = ph.VectorStore.clustered(NQ, DIM, seed=42, first=2 ** 33, n_clusters=70).read()
+    q = ph.VectorStore.clustered(NQ, DIM, seed=42, first=2 ** 33, n_clusters=400).read()
     sp = ph.SearchParameters(32, 20, 2)  # upper_layer_candidate_count != number_of_candidates on purpose
     before = two_launch_count()
     two = h.search_batch(queries=q, sp=sp, stats=True)
