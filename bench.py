@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--dataset", default="clustered", choices=["clustered", "iid"])
     ap.add_argument("--ef", type=int, default=0, help="fix number_of_candidates (0 = sweep for recall@10>=0.95)")
     ap.add_argument("--probe-depth", type=int, default=0)
+    ap.add_argument("--upper", type=int, default=0, help="upper_layer_candidate_count with --ef (0 = same as --ef)")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--skip-iid", dest="no_iid", action="store_true", help="skip the secondary iid-uniform measurement")
@@ -160,36 +161,42 @@ def main():
         cal_gt = ground_truth(store, cal)
         cal_run = Runner(index, cal)
         if args.ef:
-            grid = [(args.ef, args.probe_depth or 2)]
+            grid = [(args.ef, args.upper or args.ef, args.probe_depth or 2)]
         else:
-            grid = [(64, 2), (128, 2), (128, 4), (128, 8), (200, 4), (300, 2), (300, 4), (200, 8), (300, 8),
+            # (number_of_candidates, upper_layer_candidate_count, probe_depth): the reference's three
+            # SearchParameters (parameters.rs:3-14); its default keeps the upper count equal to the
+            # bottom one, a narrower upper queue is the classic HNSW setting
+            base = [(64, 2), (128, 2), (128, 4), (128, 8), (200, 4), (300, 2), (300, 4), (200, 8), (300, 8),
                     (128, 16), (300, 16), (512, 16), (512, 32), (1024, 64)]
+            # (measured: a narrower upper count does not help -- the reference searches every layer with a
+            # queue of number_of_candidates and only truncates its output, lib.rs:258-276)
+            grid = [(ef, ef, pd) for ef, pd in base]
         sweep, chosen = [], None
-        for ef, pd in grid:
-            sp = ph.SearchParameters(ef, ef, pd)
+        for ef, up, pd in grid:
+            sp = ph.SearchParameters(ef, up, pd)
             cal_run.launch(sp)
             cal_run.launch(sp)
             torch.cuda.synchronize()
             ms = index.kernel_ms()
             rec = recall_at_10(cal_run.result_ids(ef), cal_gt)
             qps = cal.n / ms * 1e3
-            sweep.append({"ef": ef, "probe_depth": pd, "recall_at_10": round(rec, 4), "qps_cal": round(qps)})
-            log("sweep ef=%d pd=%d recall@10=%.4f  %.0f q/s" % (ef, pd, rec, qps))
+            sweep.append({"ef": ef, "upper": up, "probe_depth": pd, "recall_at_10": round(rec, 4), "qps_cal": round(qps)})
+            log("sweep ef=%d upper=%d pd=%d recall@10=%.4f  %.0f q/s" % (ef, up, pd, rec, qps))
             # fastest setting that meets the target; settings within 3 % count as equal and the
-            # earlier (smaller queue) one is kept, so that run-to-run noise does not flip the choice
-            if rec >= args.target_recall and (chosen is None or qps > 1.03 * chosen[2]):
-                chosen = (ef, pd, qps, rec)
+            # earlier one is kept, so that run-to-run noise does not flip the choice
+            if rec >= args.target_recall and (chosen is None or qps > 1.03 * chosen[3]):
+                chosen = (ef, up, pd, qps, rec)
         met = chosen is not None
         if not met:  # report honestly at the BASELINE configuration ef_search=128
             e = [s for s in sweep if s["ef"] == 128 and s["probe_depth"] == 2] or sweep[:1]
-            chosen = (e[0]["ef"], e[0]["probe_depth"], e[0]["qps_cal"], e[0]["recall_at_10"])
-        ef, pd = chosen[0], chosen[1]
+            chosen = (e[0]["ef"], e[0]["upper"], e[0]["probe_depth"], e[0]["qps_cal"], e[0]["recall_at_10"])
+        ef, up, pd = chosen[0], chosen[1], chosen[2]
         if world > 1:
             # the sweep is timing based: all ranks adopt rank 0's choice (outside the timed region)
-            t = torch.tensor([ef, pd, int(met)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            t = torch.tensor([ef, up, pd, int(met)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.broadcast(t, src=0)
-            ef, pd, met = int(t[0]), int(t[1]), bool(int(t[2]))
-        sp = ph.SearchParameters(ef, ef, pd)
+            ef, up, pd, met = int(t[0]), int(t[1]), int(t[2]), bool(int(t[3]))
+        sp = ph.SearchParameters(ef, up, pd)
         # this rank's own query batch (weak scaling: fixed work per GPU)
         qstore = make_store(kind, args.nq, 2 ** 32 + rank * args.nq)
         run = Runner(index, qstore, ef_max=ef)
@@ -245,7 +252,7 @@ def main():
         alg_bytes = n_dist * row_bytes + n_hops * w0 * 4 + args.nq * ef * 12
         k_ms = float(np.mean(kms))
         out = {
-            "dataset": kind, "ef": ef, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
+            "dataset": kind, "ef": ef, "upper": up, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
             "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
         }
@@ -261,8 +268,9 @@ def main():
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "search_kernel_summary.json"))):
             pm = json.load(open(f)).get("pmc", {})
             w = pm.get("workload", {})
-            if (w.get("dataset"), w.get("n"), w.get("dim"), w.get("nq"), w.get("ef"), w.get("probe_depth")) == (
-                    res["dataset"], args.n, args.dim, args.nq, res["ef"], res["probe_depth"]):
+            if (w.get("dataset"), w.get("n"), w.get("dim"), w.get("nq"), w.get("ef"), w.get("upper"),
+                    w.get("probe_depth")) == (res["dataset"], args.n, args.dim, args.nq, res["ef"], res["upper"],
+                                              res["probe_depth"]):
                 traffic = pm.get("traffic_bytes_per_launch")
     except Exception:
         traffic = None
@@ -370,6 +378,7 @@ def main():
         del run, gt, qstore, index, store
         torch.cuda.empty_cache()
         saved = (args.ef, args.probe_depth)
+        args.upper = 0
         args.ef, args.probe_depth = 128, 2
         r2, *_ = measure_dataset("iid", False)
         args.ef, args.probe_depth = saved
@@ -398,7 +407,7 @@ def main():
                             % (args.n, args.dim, args.nq),
                 "dataset": "%s synthetic (1000 unit centres + uniform noise, normalised)" % res["dataset"]
                            if res["dataset"] == "clustered" else "iid uniform(-1,1) normalised (bigvec.rs:59-65)",
-                "number_of_candidates": res["ef"], "upper_layer_candidate_count": res["ef"],
+                "number_of_candidates": res["ef"], "upper_layer_candidate_count": res["upper"],
                 "probe_depth": res["probe_depth"],
                 "build": "reference defaults order=12 M=24 M0=48 ef_link=300 (parameters.rs:50-64), built on GPU",
                 "parallelism": "replicated index, queries sharded x%d; steps issued on 2 streams" % world,

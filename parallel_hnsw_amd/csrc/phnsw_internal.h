@@ -163,8 +163,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      float hit_eps = 0.f, const uint32_t *order = nullptr);
 // locality schedule helpers (group.hip / api.hip)
 #define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
-#define PH_POS_MIN 1024u     // smaller layers carry no cells (their node id is the key)
-#define PH_SPLIT_MIN 32768u  // a layer at least this large gets a launch of its own in a split descent
+#define PH_POS_MIN 256u     // smaller layers carry no cells (their node id is the key)
+#define PH_SPLIT_MIN 32768u // a layer at least this large gets a launch of its own in a split descent
 int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip
 void ph_store_anchors_free(phnsw_store *s);
 int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st);

@@ -74,7 +74,8 @@ def main():
                          "python3 bench.py (same flags, --steps 5 --warmup 1)")
         w = bench["config"]
         pm["workload"] = {"dataset": "clustered", "n": 1000000, "dim": 768, "nq": bench.get("queries_per_step_per_gpu"),
-                          "ef": w["number_of_candidates"], "probe_depth": w["probe_depth"]}
+                          "ef": w["number_of_candidates"], "upper": w["upper_layer_candidate_count"],
+                          "probe_depth": w["probe_depth"]}
         pm["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
     summary["pmc"] = pm
     os.makedirs(out_dir, exist_ok=True)
