@@ -421,6 +421,10 @@ def main():
             "hops_per_query": round(res["n_hops_per_query"], 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         # measured HBM bytes (PMC pass) over the same launch time
+                         "traffic_gbs": round(traffic / (res["kernel_ms"] * 1e-3) / 1e9, 1) if traffic else None,
+                         "traffic_frac": round(traffic / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                         if traffic else None,
                          "kernel": "ph_search_kernel", "kernel_ms": round(res["kernel_ms"], 4),
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
                          # batches >= 32768 queries descend in several dispatches of the same kernel (small top

@@ -19,3 +19,8 @@ echo "write pass done"
 python3 $ROOT/scripts/make_profile_summary.py $OUT $OUT/summary
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
+# index construction alone (1M x 768 clustered, single GPU): per-kernel totals
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/build -o b -- python3 $ROOT/scripts/probe_plain_build.py > $OUT/build.log 2>&1
+cp $OUT/build/*kernel_stats.csv $OUT/summary/kernel_stats_build.csv 2>/dev/null || find $OUT/build -name "*kernel_stats.csv" -exec cp {} $OUT/summary/kernel_stats_build.csv \;
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+tail -1 $OUT/build.log
