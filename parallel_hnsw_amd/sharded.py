@@ -157,19 +157,30 @@ class GpuEngine:
 class ShardedBuilder:
     """Hnsw::generate with every per-node phase split over the ranks of `comm`"""
 
-    def __init__(self, engine, comm=None):
+    def __init__(self, engine, comm=None, shard_min=None):
         self.e = engine
         self.comm = comm or TorchComm()
+        if shard_min is not None:
+            self.SHARD_MIN = shard_min
         self.rank, self.world = self.comm.rank, self.comm.world
         self.bp = engine.bp
 
+    # Work lists shorter than this are not split: a launch over a few thousand queries takes one
+    # query-latency however few of them a rank keeps, so every rank runs the whole (identical)
+    # list and the phase needs no collective at all.
+    SHARD_MIN = 16384
+
     def _range(self, n):
+        if n < self.SHARD_MIN:
+            return n, 0, n
         chunk = -(-n // self.world)
         first = min(n, self.rank * chunk)
         count = min(n, first + chunk) - first
         return chunk, first, count
 
     def _gather(self, t, n):
+        if n < self.SHARD_MIN:
+            return t[:n]
         return self.comm.all_gather(t)[:n]
 
     # generate_layer  lib.rs:675-823
@@ -203,7 +214,8 @@ class ShardedBuilder:
         chunk, first, count = self._range(selection)
         hits, sel = self.e.recall_hits(at, op, first, count)
         assert sel == selection, (sel, selection)
-        (hits,) = self.comm.all_reduce_sum([hits], getattr(self.e, "device", "cpu"))
+        if selection >= self.SHARD_MIN:
+            (hits,) = self.comm.all_reduce_sum([hits], getattr(self.e, "device", "cpu"))
         return float(np.float32(hits) / np.float32(selection))
 
     # improve_neighbors_upto  lib.rs:1515-1544

@@ -87,6 +87,8 @@ class OracleEngine:
 CASES = [
     dict(n=700, dim=16, kw=dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12, seed=3)),
     dict(n=1501, dim=24, kw=dict(seed=1)),   # odd size: ranges of unequal length
+    # short work lists stay whole on every rank (no collective), the bottom layer is split
+    dict(n=1500, dim=16, kw=dict(seed=2), shard_min=400),
     # duplicate-heavy data: rows cannot hold every copy, nodes stay unreachable, promotion
     # (lib.rs:1273-1427) extends and re-tops the upper layers while the build is sharded
     dict(n=1200, dim=16, dup=40, kw=dict(order=6, neighborhood_size=4, zero_layer_neighborhood_size=8, seed=1),
@@ -125,7 +127,7 @@ def _worker(rank, world, port, case, out_dir):
         bp = _case_bp(case)
         eng = OracleEngine(rows, case["dim"], bp)
         comm = TorchComm()
-        b = ShardedBuilder(eng, comm)
+        b = ShardedBuilder(eng, comm, shard_min=case.get("shard_min", 0))
         b.generate(np.arange(case["n"], dtype=np.uint64))
         layers = [eng.ix.layer(l) for l in range(eng.ix.layer_count)]
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), count=len(layers), gathered=comm.bytes_gathered,
@@ -135,7 +137,7 @@ def _worker(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d" % c["n"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d%s" % (c["n"], "-min%d" % c["shard_min"] if "shard_min" in c else ""))
 def test_sharded_build_equals_single_process(case, tmp_path):
     import torch.multiprocessing as mp
     import oracle
@@ -174,7 +176,7 @@ def test_range_split_covers_everything():
         for w in (1, 2, 3, 8):
             seen = []
             for r in range(w):
-                b = ShardedBuilder(FakeEngine(), FakeComm(r, w))
+                b = ShardedBuilder(FakeEngine(), FakeComm(r, w), shard_min=0)
                 chunk, first, count = b._range(n)
                 assert count <= chunk and first + count <= n
                 assert first == min(n, r * chunk)
