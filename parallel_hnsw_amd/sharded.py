@@ -168,7 +168,7 @@ class ShardedBuilder:
     # Work lists shorter than this are not split: a launch over a few thousand queries takes one
     # query-latency however few of them a rank keeps, so every rank runs the whole (identical)
     # list and the phase needs no collective at all.
-    SHARD_MIN = 16384
+    SHARD_MIN = 4096
 
     def _range(self, n):
         if n < self.SHARD_MIN:

@@ -241,7 +241,7 @@ def _two_rank_worker(rank, world, port, out_dir):
         store = ph.VectorStore.synthetic(n, dim, seed=42)
         eng = ph.GpuEngine(store, ph.BuildParameters(seed=6))
         comm = ph.TorchComm()
-        h = ph.ShardedBuilder(eng, comm).generate(np.arange(n))
+        h = ph.ShardedBuilder(eng, comm, shard_min=256).generate(np.arange(n))  # split all but the tiny layers
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered,
                  **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
     finally:
