@@ -360,13 +360,13 @@ def main():
                     break
             m_ = qh.store.m
             bq = best["distance_evals_per_query"] * m_ + best["hops_per_query"] * 48 * 4 + best["ef"] * (store.ld * 4 + 12)
-            pq = {"workload": "configs[4]: %dx%d PQ m=%d, 8-bit codes (%d B/vector), f16 table %d KiB in LDS, "
+            pq = {"workload": "configs[4]: %dx%d PQ m=%d, 8-bit codes (%d B/vector), f16 table %d KiB per wave in global memory (L2), "
                               "search over codes + f32 re-rank, built without promotion" % (
                                   args.n, args.dim, m_, m_, m_ * 256 * 2 // 1024),
                   "build_s": round(pq_build, 1), "recall_target_met": best.pop("met"), **best,
                   "algorithmic_bytes_per_query": round(bq),
                   "roofline_gbs": round(best["queries_per_s"] * bq / 1e9, 1),
-                  "note": "latency bound: the 48 KiB f16 table allows three resident waves per CU"}
+                  "note": "bound by L2->L1 streaming of the per-wave tables (16 tables of 48 KiB per CU, 32 KiB L1)"}
             del qh, pids, pd_
         except Exception as exc:
             pq = {"error": repr(exc)}

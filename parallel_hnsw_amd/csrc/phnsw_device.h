@@ -182,6 +182,7 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
 //                rows, one LANE per candidate, distance = sum_j T[j][code_j] added in j order.
 template <int NV>
 struct DistF32 {
+  static constexpr bool GLOBAL_TABLE = false;
   float4 qv[NV];
   __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *, uint32_t lane) {
 #pragma unroll
@@ -252,8 +253,14 @@ __host__ __device__ inline float ph_f16_bits_to_f32(uint16_t h) {
   return v.f;
 }
 
-struct DistPQ {
-  float *T;  // LDS [m][ksub] (f32) or the same region viewed as uint16_t [m][ksub]
+template <bool GLOBAL>
+struct DistPQT {
+  // GLOBAL = false: the table lives in LDS (one per wave: 48-96 KiB, so 1-3 waves per CU);
+  // GLOBAL = true: in a per-wave slot of HBM-backed memory that stays in L2 -- the batched search
+  // uses this one: the lookups become 2- or 4-byte gathers from L2, and the CU holds as many
+  // searching waves as its registers allow instead of as many tables as its LDS allows
+  static constexpr bool GLOBAL_TABLE = GLOBAL;
+  float *T;  // [m][ksub] (f32) or the same region viewed as uint16_t [m][ksub]
   // q_sub_j comes from `q` (raw query, dim floats) or from the codebook entry of a stored code
   __device__ __forceinline__ void build(const PhDistArgs &d, const float *q, const uint8_t *qcodes, float *lds,
                                         uint32_t lane) {
@@ -280,7 +287,13 @@ struct DistPQ {
           T[j * d.ksub + k] = acc;
       }
     }
-    __syncthreads();
+    if (GLOBAL) {
+      // own stores out to L2, then drop this CU's L1 lines (the slot held the previous query's table)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {
+      __syncthreads();
+    }
   }
   __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *lds, uint32_t lane) {
     build(d, q, nullptr, lds, lane);
@@ -309,3 +322,5 @@ struct DistPQ {
     return r;
   }
 };
+typedef DistPQT<false> DistPQ;
+typedef DistPQT<true> DistPQG;

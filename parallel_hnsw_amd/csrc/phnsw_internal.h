@@ -91,6 +91,8 @@ struct PhWorkspace {
   uint32_t *counter = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  void *pq_tables = nullptr;  // n_slots x table bytes (PQ stores)
+  size_t pq_tables_bytes = 0;
   // two-launch descents: per-query locality keys, their argsort, radix-sort scratch
   uint32_t *okey = nullptr, *okey_sorted = nullptr, *oiota = nullptr, *oorder = nullptr;
   void *sort_tmp = nullptr;
@@ -143,6 +145,8 @@ struct PhSearchArgs {
   uint32_t cap_max;     // threshold_nn: largest queue capacity the launch must support (0 = ef)
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
+  void *pq_tables;              // PQ store: per-wave lookup-table slots in global memory (DistPQG)
+  uint32_t pq_table_bytes;      // bytes per slot
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip
   uint32_t *out_key;            // nullable: locality key of each query after layer_hi - 1
   const uint32_t *key_pos;      // nullable: pos[] of layer layer_hi - 1
@@ -193,6 +197,11 @@ static inline PhDistArgs ph_dist_args(const phnsw_store *s) {
   d.dsub = s->pq_dsub;
   d.table_f16 = s->pq_table_f16;
   return d;
+}
+// the batched search keeps PQ tables in global memory unless PHNSW_PQ_TABLE=lds
+static inline bool ph_pq_global_tables() {
+  const char *e = getenv("PHNSW_PQ_TABLE");
+  return !(e && e[0] == 'l');
 }
 static inline size_t ph_pq_lds_bytes(const phnsw_store *s) {
   return s->codes ? (size_t)s->pq_m * s->pq_ksub * (s->pq_table_f16 ? 2 : 4) : 0;

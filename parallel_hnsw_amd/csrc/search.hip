@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   float *Qd = (float *)(smem + 3 * CAP);   //
   uint32_t *S = smem + 4 * CAP;            // prefix scratch [CAP + 64]
   float *dist_lds = (float *)(smem + 5 * CAP + 64);  // DistPQ: the query's lookup table
+  if (Dist::GLOBAL_TABLE) dist_lds = (float *)((char *)a.pq_tables + (size_t)blockIdx.x * a.pq_table_bytes);
 
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
@@ -552,7 +553,8 @@ static ph_search_fn pick_kernel(int capc, int nv) {
 #define PH_K(C, N) \
   if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, DistF32<N>>;
 #define PH_KQ(C) \
-  if (capc == C && nv == 0) return (ph_search_fn)ph_search_kernel<C, DistPQ>;
+  if (capc == C && nv == 0)   \
+    return ph_pq_global_tables() ? (ph_search_fn)ph_search_kernel<C, DistPQG> : (ph_search_fn)ph_search_kernel<C, DistPQ>;
   PH_K(2, 1) PH_K(2, 3) PH_K(2, 6)
   PH_K(8, 1) PH_K(8, 3) PH_K(8, 6)
   PH_K(16, 1) PH_K(16, 3) PH_K(16, 6)
@@ -594,6 +596,7 @@ void ph_workspace_free(PhWorkspace &ws) {
   if (ws.visited) hipFree(ws.visited);
   if (ws.ovf) hipFree(ws.ovf);
   if (ws.counter) hipFree(ws.counter);
+  if (ws.pq_tables) hipFree(ws.pq_tables);
   if (ws.ev0) hipEventDestroy(ws.ev0);
   if (ws.ev1) hipEventDestroy(ws.ev1);
   ph_workspace_order_free(ws);
@@ -604,7 +607,9 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   uint64_t max_nodes = 0;
   for (auto &l : ix->layers) max_nodes = std::max<uint64_t>(max_nodes, l.n_nodes);
   uint64_t words = (max_nodes + 31) / 32 + 1;
-  uint32_t slots = ph_search_slots(ef, ix->store->ld / 4, ix->store->codes != nullptr, ph_pq_lds_bytes(ix->store));
+  const bool pqg = ix->store->codes != nullptr && ph_pq_global_tables();
+  uint32_t slots = ph_search_slots(ef, ix->store->ld / 4, ix->store->codes != nullptr,
+                                   pqg ? 0 : ph_pq_lds_bytes(ix->store));
   if (slots == 0) {
     ph_set_error("unsupported search shape: ef=%u dim=%u (ef <= 1024, dim <= 1536; PQ table + queue <= 160 KB LDS)", ef,
                  ix->store->dim);
@@ -629,6 +634,12 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
     ws.n_slots = ns;
     ws.visited_words = nw;
   }
+  if (pqg && ws.pq_tables_bytes < (size_t)ws.n_slots * ph_pq_lds_bytes(ix->store)) {
+    if (ws.pq_tables) PH_HIP(hipFree(ws.pq_tables));
+    ws.pq_tables = nullptr;
+    ws.pq_tables_bytes = (size_t)ws.n_slots * ph_pq_lds_bytes(ix->store);
+    PH_HIP(hipMalloc(&ws.pq_tables, ws.pq_tables_bytes));
+  }
   if (!ws.ovf || ws.ovf_cap < ovf_cap) {
     if (ws.ovf) PH_HIP(hipFree(ws.ovf));
     ws.ovf = nullptr;
@@ -641,7 +652,9 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_begin,
                      bool mark_end) {
   const bool pq = ix->store->codes != nullptr;
-  const size_t pq_lds = ph_pq_lds_bytes(ix->store);
+  const size_t pq_lds = (pq && ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store);
+  a.pq_tables = ws.pq_tables;
+  a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
   ph_search_fn fn = (capc && (pq || nv)) ? pick_kernel(capc, nv) : nullptr;
   if (!fn) {
