@@ -255,6 +255,8 @@ def main():
             "dataset": kind, "ef": ef, "upper": up, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
             "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
+            "dispatches": (1 + sum(1 for l in range(1, index.layer_count()) if index._layer(l).node_count() >= 32768))
+            if args.nq >= 32768 else 1,
         }
         return out, store, index, qstore, run, sp, gt
 
@@ -429,9 +431,7 @@ def main():
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
                          # batches >= 32768 queries descend in several dispatches of the same kernel (small top
                          # layers; then each large layer in locality order): kernel_ms spans all (HIP events)
-                         "dispatches_per_launch": (1 + sum(1 for l in range(1, index.layer_count())
-                                                          if index._layer(l).node_count() >= 32768))
-                         if args.nq >= 32768 else 1,
+                         "dispatches_per_launch": res["dispatches"],
                          "note": "achieved = algorithmic bytes / time; it can exceed the HBM peak because "
                                  "neighbouring queries are scheduled together and share rows in L2 / the Infinity "
                                  "Cache (traffic = measured HBM bytes)",
