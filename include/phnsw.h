@@ -98,6 +98,10 @@ int phnsw_device_count(void);
  * rows are copied into one flat HBM array [n][ld], ld = dim rounded up to 4 floats. */
 int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, int metric, int device,
                        phnsw_store **out);
+/* append rows to a store that owns its array (ids continue at the old n; *out_first_id = first
+ * new VectorId).  The reference grows the Vec behind its comparator the same way before it
+ * indexes new ids (src/bigvec.rs:38-44).  Not concurrent with searches/builds on this store. */
+int phnsw_store_append(phnsw_store *s, const float *rows, uint64_t count, uint64_t *out_first_id);
 /* adopt an existing device array (e.g. a torch tensor); caller keeps it alive */
 int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, uint32_t ld,
                               int metric, int device, phnsw_store **out);

@@ -82,6 +82,13 @@ class Comparator {
     check(phnsw_distance_batch(s_, v.stored ? nullptr : v.vec, v.id, ids.data(), ids.size(), out.data()));
     return out;
   }
+  // more vectors behind the same comparator; returns the first new VectorId
+  VectorId append(const float *rows, uint64_t count) {
+    uint64_t first = 0;
+    check(phnsw_store_append(s_, rows, count, &first));
+    n_ += count;
+    return first;
+  }
   // exact k nearest (ground truth for recall@k)
   std::vector<std::vector<std::pair<VectorId, float>>> bruteforce(const std::vector<float> &queries, uint32_t k) const {
     uint64_t nq = queries.size() / dim_;

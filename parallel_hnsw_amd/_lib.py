@@ -49,6 +49,7 @@ SYMBOLS = {
     "phnsw_last_error": (C.c_char_p, []),
     "phnsw_device_count": (_i32, []),
     "phnsw_store_create": (_i32, [_vp, _u64, _u32, _i32, _i32, _pp]),
+    "phnsw_store_append": (_i32, [_vp, _vp, _u64, _vp]),
     "phnsw_store_create_device": (_i32, [_vp, _u64, _u32, _u32, _i32, _i32, _pp]),
     "phnsw_store_create_synthetic": (_i32, [_u64, _u64, _u32, _u64, _i32, _i32, _i32, _pp]),
     "phnsw_store_create_clustered": (_i32, [_u64, _u64, _u32, _u64, _u32, _f32, _i32, _i32, _pp]),

@@ -136,6 +136,44 @@ extern "C" int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, i
   return 0;
 }
 
+// more rows for a store that owns its array (the reference grows `Vec<Vec<f32>>` behind the
+// comparator and calls generate / extend on the new ids): the array is reallocated, so no search
+// or build may be running on an index over this store; existing VectorIds keep their rows
+extern "C" int phnsw_store_append(phnsw_store *s, const float *rows, uint64_t count, uint64_t *out_first_id) {
+  if (!s || !rows || !s->rows || !s->owns_rows || s->n + count >= 0x7FFFFFFFull) {
+    ph_set_error("phnsw_store_append: needs an f32 store created by phnsw_store_create* that owns its rows, n < 2^31");
+    return PHNSW_E_INVALID;
+  }
+  if (out_first_id) *out_first_id = s->n;
+  if (count == 0) return 0;
+  int rc = use_device(s->device);
+  if (rc) return rc;
+  float *grown = nullptr;
+  const size_t ldb = (size_t)s->ld * 4;
+  hipError_t e = hipMalloc(&grown, (size_t)(s->n + count) * ldb);
+  if (e == hipSuccess) e = hipMemcpy(grown, s->rows, (size_t)s->n * ldb, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess && s->ld != s->dim) e = hipMemset(grown + (size_t)s->n * s->ld, 0, (size_t)count * ldb);
+  if (e == hipSuccess)
+    e = hipMemcpy2D(grown + (size_t)s->n * s->ld, ldb, rows, (size_t)s->dim * 4, (size_t)s->dim * 4, count,
+                    hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (grown) hipFree(grown);
+    return ph_hip_fail(e, "store append", __FILE__, __LINE__);
+  }
+  phnsw_store tail = *s;  // NaN check over the new rows only
+  tail.rows = grown + (size_t)s->n * s->ld;
+  tail.n = count;
+  rc = store_check_nan(&tail);
+  if (rc) {
+    hipFree(grown);
+    return rc;
+  }
+  hipFree(s->rows);
+  s->rows = grown;
+  s->n += count;
+  return 0;
+}
+
 extern "C" int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, uint32_t ld, int metric,
                                          int device, phnsw_store **out) {
   if (!out || !rows_dev || dim == 0 || n == 0 || ld < dim || (ld % 4) || metric < 0 || metric > 2 ||

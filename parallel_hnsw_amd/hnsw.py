@@ -66,11 +66,23 @@ class VectorStore:
             rows = np.ascontiguousarray(rows, dtype=np.float32)
             assert rows.ndim == 2
             check(lib().phnsw_store_create(_p(rows), rows.shape[0], rows.shape[1], metric, device, C.byref(self._h)))
+        self.device = device
+        self._refresh()
+
+    def _refresh(self):
         n, dim, ld, m = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_int()
         ptr = C.c_void_p()
         check(lib().phnsw_store_info(self._h, C.byref(n), C.byref(dim), C.byref(ld), C.byref(m), C.byref(ptr)))
         self.n, self.dim, self.ld, self.metric, self.rows_dev = n.value, dim.value, ld.value, m.value, ptr.value
-        self.device = device
+
+    def append(self, rows):
+        """more vectors behind the same comparator; returns the first new VectorId"""
+        rows = np.ascontiguousarray(np.atleast_2d(rows), dtype=np.float32)
+        assert rows.shape[1] == self.dim
+        first = C.c_uint64()
+        check(lib().phnsw_store_append(self._h, _p(rows), rows.shape[0], C.byref(first)))
+        self._refresh()
+        return first.value
 
     @classmethod
     def synthetic(cls, n, dim, seed=42, first=0, normalize=True, metric=METRIC_COSINE_HALF, device=0):

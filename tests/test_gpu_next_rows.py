@@ -107,3 +107,27 @@ def test_serialize_layout_and_roundtrip(tmp_path):
     assert "not found" in str(e.value).lower()
     with pytest.raises(ph.PhnswError):
         ph.Hnsw.deserialize(tmp_path / "nothing-here", store)
+
+
+def test_store_append_keeps_ids_and_matches_a_whole_store():
+    """phnsw_store_append: the grown store behaves exactly like one created with all rows"""
+    rows = oracle.synth_rows(0, 800, 40)[:, :40]
+    whole = ph.VectorStore(rows)
+    grown = ph.VectorStore(rows[:500])
+    assert grown.append(rows[500:]) == 500
+    assert grown.n == 800
+    np.testing.assert_array_equal(grown.read().view(np.uint32), whole.read().view(np.uint32))
+    ids = np.arange(800, dtype=np.uint64)
+    np.testing.assert_array_equal(grown.compare_vec(ph.Stored(3), ids).view(np.uint32),
+                                  whole.compare_vec(ph.Stored(3), ids).view(np.uint32))
+    bp = ph.BuildParameters(seed=3)
+    a = ph.Hnsw.generate(grown, ids, bp)
+    b = ph.Hnsw.generate(whole, ids, bp)
+    for x, y in zip(a.layers, b.layers):
+        np.testing.assert_array_equal(x.nodes, y.nodes)
+        np.testing.assert_array_equal(x.neighbors, y.neighbors)
+    bad = rows[:2].copy()
+    bad[1, 5] = np.nan
+    with pytest.raises(ph.PhnswError):
+        grown.append(bad)
+    assert grown.n == 800
