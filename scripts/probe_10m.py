@@ -30,3 +30,15 @@ for ef, pd in [(128, 2), (128, 8), (300, 8)]:
     rec = float((r[:, :, None] == bi[:, None, :]).any(2).float().mean())
     ms = h.kernel_ms()
     print("ef", ef, "pd", pd, "recall@10 %.4f" % rec, "qps %.0f" % (nq / ms * 1e3), "ndist %.0f" % st[:, 0].float().mean(), "status", int(status.sum()), flush=True)
+
+# a 100 000-query batch: split, cell-ordered descent
+nq2 = 100000
+qs2 = ph.VectorStore.clustered(nq2, dim, first=2 ** 33, n_clusters=10000)
+ids2 = torch.empty((nq2, 300), dtype=torch.int32, device="cuda"); d2 = torch.empty((nq2, 300), device="cuda")
+ln2 = torch.empty(nq2, dtype=torch.int32, device="cuda"); st2 = torch.empty((nq2, 2), dtype=torch.int32, device="cuda"); status2 = torch.empty(nq2, dtype=torch.int32, device="cuda")
+for ef, pd in [(128, 8), (300, 8)]:
+    sp = ph.SearchParameters(ef, ef, pd)
+    for _ in range(2):
+        h.search_batch_device(nq2, sp, ids2.data_ptr(), d2.data_ptr(), ln2.data_ptr(), status2.data_ptr(), queries=qs2.rows_dev, ldq=dim, out_stats=st2.data_ptr())
+        torch.cuda.synchronize()
+    print("100k batch ef", ef, "pd", pd, "qps %.0f" % (nq2 / h.kernel_ms() * 1e3), "ndist %.0f" % st2[:, 0].float().mean(), "status", int(status2.sum()), flush=True)

@@ -8,7 +8,8 @@ import parallel_hnsw_amd as ph
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 dim, m = 768, 96
 full = ph.VectorStore.clustered(n, dim)
-t = time.time(); qh = ph.QuantizedHnsw(256, full, ph.BuildParameters(promote=0), m=m); torch.cuda.synchronize()  # promotion off: DESIGN section 9
+f16 = len(sys.argv) > 2 and sys.argv[2] == 'f16'
+t = time.time(); qh = ph.QuantizedHnsw(256, full, ph.BuildParameters(promote=0), m=m, table_f16=f16); torch.cuda.synchronize()  # promotion off: DESIGN section 9
 print("pq create+build s", time.time() - t, flush=True)
 qs = ph.VectorStore.clustered(10000, dim, first=2 ** 32)
 class D:
