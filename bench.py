@@ -239,6 +239,24 @@ def main():
             run.launch(sp)
             torch.cuda.synchronize()
             kms.append(index.kernel_ms())
+        # latency side of the same path (batch sizes 1, 64, 1 024, 10 000): one
+        # isolated launch per measurement, the first nq queries of the timed batch
+        batch_sweep = []
+        if headline and rank == 0:
+            for b in (1, 64, 1024, 10000):
+                if b > args.nq:
+                    break
+                ms = []
+                for _ in range(5):
+                    index.search_batch_device(b, sp, run.ids.data_ptr(), run.d.data_ptr(), run.len.data_ptr(),
+                                              run.status.data_ptr(), queries=qstore.rows_dev, ldq=qstore.ld,
+                                              out_stats=run.stats.data_ptr(), stream=stream)
+                    torch.cuda.synchronize()
+                    ms.append(index.kernel_ms())
+                batch_sweep.append({"queries": b, "kernel_ms": round(min(ms), 3), "queries_per_s": round(b / min(ms) * 1e3)})
+            run.launch(sp)  # restore the full batch's results for the recall / counters below
+            torch.cuda.synchronize()
+            log("batch sweep: " + ", ".join("%d: %.2f ms" % (x["queries"], x["kernel_ms"]) for x in batch_sweep))
         if world > 1:
             t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -255,6 +273,7 @@ def main():
             "dataset": kind, "ef": ef, "upper": up, "probe_depth": pd, "recall_target_met": met, "recall_at_10": round(rec, 4),
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
             "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
+            "batch_sweep": batch_sweep,
             "dispatches": (1 + sum(1 for l in range(1, index.layer_count()) if index._layer(l).node_count() >= 32768))
             if args.nq >= 32768 else 1,
         }
@@ -441,6 +460,7 @@ def main():
             "cpu_baseline": cpu,
             "secondary": iid,
             "pq": pq,
+            "batch_sweep": res["batch_sweep"],
             "sweep": res["sweep"],
         }
         print(json.dumps(line), flush=True)
