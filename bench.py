@@ -353,6 +353,9 @@ def main():
             torch.cuda.synchronize()
             pq_build = time.time() - t0
             log("pq: codebooks + codes + graph over codes in %.1f s" % pq_build)
+            # the graph is built with the exact f32 table (symmetric distances); queries are then
+            # scored through 8-bit table entries (phnsw_pq_set_table_mode 2: search-only, asymmetric)
+            qh.store.set_table_mode("u8")
             ef_max = 1024
             pids = torch.empty((args.nq, ef_max), dtype=torch.int32, device=dev)
             pd_ = torch.empty((args.nq, ef_max), dtype=torch.float32, device=dev)
@@ -380,13 +383,14 @@ def main():
                     break
             m_ = qh.store.m
             bq = best["distance_evals_per_query"] * m_ + best["hops_per_query"] * 48 * 4 + best["ef"] * (store.ld * 4 + 12)
-            pq = {"workload": "configs[4]: %dx%d PQ m=%d, 8-bit codes (%d B/vector), f32 table %d KiB per wave in global memory (L2), "
-                              "search over codes + f32 re-rank, built without promotion" % (
-                                  args.n, args.dim, m_, m_, m_ * 256 * 4 // 1024),
+            pq = {"workload": "configs[4]: %dx%d PQ m=%d, 8-bit codes (%d B/vector), 8-bit per-query ADC table %d KiB per wave in "
+                              "global memory (L2), search over codes + f32 re-rank; graph built with the f32 table, without "
+                              "promotion" % (args.n, args.dim, m_, m_, m_ * 256 // 1024),
                   "build_s": round(pq_build, 1), "recall_target_met": best.pop("met"), **best,
                   "algorithmic_bytes_per_query": round(bq),
                   "roofline_gbs": round(best["queries_per_s"] * bq / 1e9, 1),
-                  "note": "bound by the L1 miss rate of the table gathers (~700 L2 requests per hop, PMC TCP_TCC_READ_REQ)"}
+                  "note": "bound by the L1 miss rate of the table gathers (PMC TCP_TCC_READ_REQ: ~700 L2 requests per hop with f32 "
+                          "entries, about half with 8-bit entries)"}
             del qh, pids, pd_
         except Exception as exc:
             pq = {"error": repr(exc)}

@@ -247,9 +247,13 @@ int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_opti
  * ksub <= 256, m*ksub*4 bytes must fit the LDS. */
 int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out);
 int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);
-/* keep the per-query lookup table as IEEE half values (half the LDS, more resident waves);
- * set it before building an index over the store */
-int phnsw_pq_set_table_f16(phnsw_store *s, int on);
+/* storage of the per-query lookup table: 0 = f32 (reference arithmetic), 1 = IEEE half entries,
+ * 2 = 8-bit entries with a per-query scale (integer sums; fewest L2 requests per hop).  Modes 1
+ * and 2 change the quantised distances.  Mode 1 must be set before building an index over the
+ * store.  Mode 2 scales by the query's own table, so d(a,b) != d(b,a): it is for SEARCHING a graph
+ * built in mode 0 or 1 (build entry points refuse it with PHNSW_E_UNSUPPORTED). */
+int phnsw_pq_set_table_mode(phnsw_store *s, int mode);
+int phnsw_pq_set_table_f16(phnsw_store *s, int on); /* = set_table_mode(s, on ? 1 : 0) */
 int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook);
 /* QuantizedHnsw::search  pq.rs:346-364 for a batch: search the index over the PQ store, re-rank
  * every result with the full-precision store, sort by (distance, id).  quantize_query != 0

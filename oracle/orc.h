@@ -57,7 +57,7 @@ typedef struct {
   const uint8_t *codes;
   const float *codebook;
   uint32_t pq_m, pq_ksub, pq_dsub;
-  uint32_t pq_table_f16; /* table entries rounded to IEEE half once */
+  uint32_t pq_table_f16; /* table mode: 0 f32, 1 entries rounded to IEEE half once, 2 8-bit entries */
 } orc_store;
 
 float orc_distance(const orc_store *s, const float *a, const float *b);

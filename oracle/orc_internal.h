@@ -44,6 +44,7 @@ typedef struct {
   /* the prepared query: f32 vector, or (PQ store) its lookup table T[m][ksub] */
   const float *qv;
   float *pq_table;
+  float pq_bias, pq_scale; /* 8-bit table mode: distance = bias + scale * sum of entries */
   float *pq_recon;
 } orc_scratch;
 

@@ -12,6 +12,7 @@
  *   d      = metric epilogue(r)
  *   code_j = argmin_k sum_e (x_sub_j[e]-c_jk[e])^2 (fma chain), ties to the smaller k
  * A Stored query is its reconstruction, which makes code-vs-code distances symmetric. */
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,23 +68,57 @@ static float round_to_f16(float f) {
   return v.f;
 }
 
-static void pq_build_table(const orc_store *S, const float *raw, const uint8_t *qcodes, float *T) {
+static float pq_entry(const orc_store *S, const float *qs, uint32_t j, uint32_t k, int l2) {
+  const float *c = S->codebook + ((uint64_t)j * S->pq_ksub + k) * S->pq_dsub;
+  float acc = 0.0f;
+  for (uint32_t e = 0; e < S->pq_dsub; e++) {
+    if (l2) {
+      float df = qs[e] - c[e];
+      acc = fmaf(df, df, acc);
+    } else {
+      acc = fmaf(qs[e], c[e], acc);
+    }
+  }
+  return acc;
+}
+
+/* table modes: 0 = f32 entries; 1 = each entry rounded to IEEE half once;
+ * 2 = 8-bit entries: u[j][k] = rint((T[j][k] - min_j) / scale), scale = (widest row range) / 255,
+ * distance = bias + scale * (integer sum), bias = sum_j min_j added in j order.  T holds the
+ * entries as floats in every mode (small integers in mode 2). */
+static void pq_build_table(const orc_store *S, const float *raw, const uint8_t *qcodes, float *T, float *bias,
+                           float *scale) {
   const int l2 = S->metric == ORC_METRIC_L2;
+  *bias = 0.0f;
+  *scale = 0.0f;
   for (uint32_t j = 0; j < S->pq_m; j++) {
     const float *qs = raw ? raw + (uint64_t)j * S->pq_dsub
                           : S->codebook + ((uint64_t)j * S->pq_ksub + qcodes[j]) * S->pq_dsub;
     for (uint32_t k = 0; k < S->pq_ksub; k++) {
-      const float *c = S->codebook + ((uint64_t)j * S->pq_ksub + k) * S->pq_dsub;
-      float acc = 0.0f;
-      for (uint32_t e = 0; e < S->pq_dsub; e++) {
-        if (l2) {
-          float df = qs[e] - c[e];
-          acc = fmaf(df, df, acc);
-        } else {
-          acc = fmaf(qs[e], c[e], acc);
-        }
-      }
-      T[j * S->pq_ksub + k] = S->pq_table_f16 ? round_to_f16(acc) : acc;
+      float acc = pq_entry(S, qs, j, k, l2);
+      T[j * S->pq_ksub + k] = S->pq_table_f16 == 1 ? round_to_f16(acc) : acc;
+    }
+  }
+  if (S->pq_table_f16 != 2) return;
+  float widest = 0.0f;
+  for (uint32_t j = 0; j < S->pq_m; j++) {
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    for (uint32_t k = 0; k < S->pq_ksub; k++) {
+      float v = T[j * S->pq_ksub + k];
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+    float range = hi - lo;
+    widest = range > widest ? range : widest;
+    *bias = *bias + lo;
+  }
+  *scale = widest / 255.0f;
+  for (uint32_t j = 0; j < S->pq_m; j++) {
+    float lo = FLT_MAX;
+    for (uint32_t k = 0; k < S->pq_ksub; k++) lo = T[j * S->pq_ksub + k] < lo ? T[j * S->pq_ksub + k] : lo;
+    for (uint32_t k = 0; k < S->pq_ksub; k++) {
+      float v = T[j * S->pq_ksub + k];
+      T[j * S->pq_ksub + k] = *scale > 0.0f ? (float)(uint8_t)rintf((v - lo) / *scale) : 0.0f;
     }
   }
 }
@@ -94,7 +129,8 @@ void orc_query_prepare(const orc_store *S, orc_scratch *sc, const float *raw, ui
     return;
   }
   if (!sc->pq_table) sc->pq_table = (float *)malloc(sizeof(float) * (size_t)S->pq_m * S->pq_ksub);
-  pq_build_table(S, raw, raw ? NULL : S->codes + stored_id * (uint64_t)S->pq_m, sc->pq_table);
+  pq_build_table(S, raw, raw ? NULL : S->codes + stored_id * (uint64_t)S->pq_m, sc->pq_table, &sc->pq_bias,
+                 &sc->pq_scale);
   sc->qv = raw;
 }
 
@@ -113,11 +149,18 @@ float orc_query_dist(const orc_store *S, const orc_scratch *sc, uint64_t vid) {
   if (!S->codes) return orc_distance(S, sc->qv, S->rows + vid * (uint64_t)S->ld);
   const uint8_t *code = S->codes + vid * (uint64_t)S->pq_m;
   float r = 0.0f;
-  for (uint32_t j = 0; j < S->pq_m; j++) r = r + sc->pq_table[j * S->pq_ksub + code[j]];
+  if (S->pq_table_f16 == 2) {
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < S->pq_m; j++) sum += (uint32_t)sc->pq_table[j * S->pq_ksub + code[j]];
+    float scaled = sc->pq_scale * (float)sum;
+    r = sc->pq_bias + scaled;
+  } else {
+    for (uint32_t j = 0; j < S->pq_m; j++) r = r + sc->pq_table[j * S->pq_ksub + code[j]];
+  }
   return metric_epilogue(S, r);
 }
 
-void orc_index_set_pq_table_f16(orc_index *ix, int on) { ix->store.pq_table_f16 = on ? 1u : 0u; }
+void orc_index_set_pq_table_f16(orc_index *ix, int on) { ix->store.pq_table_f16 = on == 2 ? 2u : (on ? 1u : 0u); }
 
 void orc_index_set_pq(orc_index *ix, const uint8_t *codes, const float *codebook, uint32_t m, uint32_t ksub,
                       uint32_t dsub) {

@@ -702,9 +702,21 @@ void ph_pending_free(phnsw_index *ix) { pending_drop(ix); }
 
 // begin: validate, sort, upload nodes + id map, allocate rows.  *needs_phases = 0 when the
 // layer was completed here (first layer of a stack: all-pairs seeding, n < order).
+// Row maintenance keeps, per row, each occupant's distance to the row owner and merges
+// proposals by (distance, id): that needs d(a, b) == d(b, a) bit for bit.  The 8-bit PQ table
+// scales by the QUERY's table, so it is for searching a graph built in mode 0 or 1.
+static int symmetric_store(const phnsw_store *s) {
+  if (s->codes && s->pq_table_f16 == 2) {
+    ph_set_error("8-bit PQ tables (phnsw_pq_set_table_mode 2) are asymmetric: build / link in mode 0 or 1, then switch");
+    return PHNSW_E_UNSUPPORTED;
+  }
+  return 0;
+}
+
 static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
                             const phnsw_build_params *bp, int *needs_phases) {
   const phnsw_store *s = ix->store;
+  PH_TRY(symmetric_store(s));
   if (!vids || n64 == 0 || W64 == 0 || W64 > 64 || n64 >= 0x7FFFFFFFull || !bp) {
     ph_set_error("generate_layer: need 1 <= n < 2^31 nodes and 1 <= neighborhood_size <= 64");
     return PHNSW_E_INVALID;
@@ -933,6 +945,7 @@ static int link_apply_impl(phnsw_index *ix, uint32_t lft, uint64_t link_count, c
     return PHNSW_E_INVALID;
   }
   PhLayerHost &L = ix->layers[lft];
+  PH_TRY(symmetric_store(ix->store));
   PH_TRY(ensure_row_dist(ix, L));
   uint32_t n = L.n_nodes, M = (uint32_t)link_count;
   DevBuf<uint32_t> tgt;

@@ -260,28 +260,69 @@ struct DistPQT {
   // uses this one: the lookups become 2- or 4-byte gathers from L2, and the CU holds as many
   // searching waves as its registers allow instead of as many tables as its LDS allows
   static constexpr bool GLOBAL_TABLE = GLOBAL;
-  float *T;  // [m][ksub] (f32) or the same region viewed as uint16_t [m][ksub]
+  float *T;  // [m][ksub] (f32) or the same region viewed as uint16_t / uint8_t [m][ksub]
+  float bias, scale;  // table mode 2 (8-bit entries): distance = bias + scale * sum of entries
+  __device__ __forceinline__ float entry(const PhDistArgs &d, const float *qs, uint32_t j, uint32_t k, bool l2) const {
+    const float *c = d.codebook + ((uint64_t)j * d.ksub + k) * d.dsub;
+    float acc = 0.f;
+    for (uint32_t e = 0; e < d.dsub; e++) {
+      if (l2) {
+        float df = qs[e] - c[e];
+        acc = fmaf(df, df, acc);
+      } else {
+        acc = fmaf(qs[e], c[e], acc);
+      }
+    }
+    return acc;
+  }
   // q_sub_j comes from `q` (raw query, dim floats) or from the codebook entry of a stored code
   __device__ __forceinline__ void build(const PhDistArgs &d, const float *q, const uint8_t *qcodes, float *lds,
                                         uint32_t lane) {
     T = lds;
     uint16_t *T16 = (uint16_t *)lds;
+    uint8_t *T8 = (uint8_t *)lds;
     const bool l2 = d.metric == PHNSW_METRIC_L2;
+    bias = 0.f;
+    scale = 0.f;
+    float rmin0 = 0.f, rmin1 = 0.f;  // row minima: row j in lane j & 63 of register j >> 6 (m <= 128)
+    if (d.table_f16 == 2) {
+      // pass 1: per-row minimum and the widest row range (exact: min / max only)
+      float widest = 0.f;
+      for (uint32_t j = 0; j < d.m; j++) {
+        const float *qs = q ? q + (uint64_t)j * d.dsub : d.codebook + ((uint64_t)j * d.ksub + qcodes[j]) * d.dsub;
+        float lo = PH_FMAX, hi = -PH_FMAX;
+        for (uint32_t k = lane; k < d.ksub; k += 64) {
+          float v = entry(d, qs, j, k, l2);
+          lo = fminf(lo, v);
+          hi = fmaxf(hi, v);
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+          lo = fminf(lo, __shfl_xor(lo, sft));
+          hi = fmaxf(hi, __shfl_xor(hi, sft));
+        }
+        widest = fmaxf(widest, __fsub_rn(hi, lo));
+        if (lane == (j & 63u)) {
+          if (j < 64)
+            rmin0 = lo;
+          else
+            rmin1 = lo;
+        }
+        bias = __fadd_rn(bias, lo);  // in j order
+      }
+      scale = __fdiv_rn(widest, 255.0f);
+    }
     for (uint32_t j = 0; j < d.m; j++) {
       const float *qs = q ? q + (uint64_t)j * d.dsub
                           : d.codebook + ((uint64_t)j * d.ksub + qcodes[j]) * d.dsub;
+      float rowmin = 0.f;
+      if (d.table_f16 == 2)
+        rowmin = __uint_as_float(rl32(__float_as_uint(j < 64 ? rmin0 : rmin1), (int)(j & 63u)));
       for (uint32_t k = lane; k < d.ksub; k += 64) {
-        const float *c = d.codebook + ((uint64_t)j * d.ksub + k) * d.dsub;
-        float acc = 0.f;
-        for (uint32_t e = 0; e < d.dsub; e++) {
-          if (l2) {
-            float df = qs[e] - c[e];
-            acc = fmaf(df, df, acc);
-          } else {
-            acc = fmaf(qs[e], c[e], acc);
-          }
-        }
-        if (d.table_f16)
+        float acc = entry(d, qs, j, k, l2);
+        if (d.table_f16 == 2)
+          T8[j * d.ksub + k] = scale > 0.f ? (uint8_t)rintf(__fdiv_rn(__fsub_rn(acc, rowmin), scale)) : (uint8_t)0;
+        else if (d.table_f16)
           T16[j * d.ksub + k] = ph_f32_to_f16_bits(acc);
         else
           T[j * d.ksub + k] = acc;
@@ -309,13 +350,27 @@ struct DistPQT {
     float r = 0.f;
     if ((mask >> lane) & 1ull) {
       const uint32_t *row = (const uint32_t *)(d.codes + (uint64_t)vid * d.m);  // m % 4 == 0
-      for (uint32_t w = 0; w < d.m / 4; w++) {
-        uint32_t cw = row[w];
-        uint32_t j = 4 * w;
-        r = __fadd_rn(r, at(d, (j + 0) * d.ksub + (cw & 0xFF)));
-        r = __fadd_rn(r, at(d, (j + 1) * d.ksub + ((cw >> 8) & 0xFF)));
-        r = __fadd_rn(r, at(d, (j + 2) * d.ksub + ((cw >> 16) & 0xFF)));
-        r = __fadd_rn(r, at(d, (j + 3) * d.ksub + (cw >> 24)));
+      if (d.table_f16 == 2) {
+        const uint8_t *T8 = (const uint8_t *)T;
+        uint32_t sum = 0;
+        for (uint32_t w = 0; w < d.m / 4; w++) {
+          uint32_t cw = row[w];
+          uint32_t j = 4 * w;
+          sum += T8[(j + 0) * d.ksub + (cw & 0xFF)];
+          sum += T8[(j + 1) * d.ksub + ((cw >> 8) & 0xFF)];
+          sum += T8[(j + 2) * d.ksub + ((cw >> 16) & 0xFF)];
+          sum += T8[(j + 3) * d.ksub + (cw >> 24)];
+        }
+        r = __fadd_rn(bias, __fmul_rn(scale, (float)sum));  // exact integer sum, two roundings
+      } else {
+        for (uint32_t w = 0; w < d.m / 4; w++) {
+          uint32_t cw = row[w];
+          uint32_t j = 4 * w;
+          r = __fadd_rn(r, at(d, (j + 0) * d.ksub + (cw & 0xFF)));
+          r = __fadd_rn(r, at(d, (j + 1) * d.ksub + ((cw >> 8) & 0xFF)));
+          r = __fadd_rn(r, at(d, (j + 2) * d.ksub + ((cw >> 16) & 0xFF)));
+          r = __fadd_rn(r, at(d, (j + 3) * d.ksub + (cw >> 24)));
+        }
       }
       r = finalize_metric(r, d.metric);
     }

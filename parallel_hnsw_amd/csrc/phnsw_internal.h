@@ -204,7 +204,7 @@ static inline bool ph_pq_global_tables() {
   return !(e && e[0] == 'l');
 }
 static inline size_t ph_pq_lds_bytes(const phnsw_store *s) {
-  return s->codes ? (size_t)s->pq_m * s->pq_ksub * (s->pq_table_f16 ? 2 : 4) : 0;
+  return s->codes ? (size_t)s->pq_m * s->pq_ksub * (s->pq_table_f16 == 2 ? 1 : (s->pq_table_f16 ? 2 : 4)) : 0;
 }
 
 // misc kernels (misc.hip)

@@ -188,17 +188,25 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   return 0;
 }
 
-// store the per-query lookup table as IEEE half values (48 KiB instead of 96 KiB at m=96,
-// ksub=256: three resident waves per CU instead of one).  Changes the quantised distances
-// (each table entry is rounded once); graphs must be built with the same setting.
-extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) {
-  if (!s || !s->codes) {
-    ph_set_error("not a product-quantised store");
+// How the per-query lookup table T[m][ksub] is stored.  0: f32, the
+// reference arithmetic.  1: every entry rounded once to IEEE half.  2: 8-bit entries
+// u = rint((T - min_row) / scale), scale = widest row range / 255; a distance is then
+// bias + scale * (exact integer sum), bias = sum of the row minima.  Modes 1 and 2 change the
+// quantised distances; a graph must be built and searched in the same mode.  The oracle mirrors
+// every mode bit for bit.
+extern "C" int phnsw_pq_set_table_mode(phnsw_store *s, int mode) {
+  if (!s || !s->codes || mode < 0 || mode > 2) {
+    ph_set_error("phnsw_pq_set_table_mode: needs a product-quantised store and mode 0 (f32), 1 (f16) or 2 (8-bit)");
     return PHNSW_E_INVALID;
   }
-  s->pq_table_f16 = on ? 1u : 0u;
+  if (mode == 2 && s->pq_m > 128) {
+    ph_set_error("8-bit tables support at most 128 sub-spaces (got %u)", s->pq_m);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  s->pq_table_f16 = (uint32_t)mode;
   return 0;
 }
+extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) { return phnsw_pq_set_table_mode(s, on ? 1 : 0); }
 
 extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) {
   if (!s || !s->codes) {

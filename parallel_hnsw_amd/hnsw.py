@@ -150,17 +150,29 @@ class VectorStore:
 class PqStore(VectorStore):
     """product-quantised view of a VectorStore (pq.rs): u8 codes over per-sub-space codebooks"""
 
-    def __init__(self, full, m, ksub=256, seed=0, table_f16=False):
+    TABLE_MODES = {"f32": 0, "f16": 1, "u8": 2}
+
+    def __init__(self, full, m, ksub=256, seed=0, table_f16=False, table_mode=None):
+        """table_mode: "f32" (reference arithmetic), "f16" or "u8" (phnsw_pq_set_table_mode)"""
         h = C.c_void_p()
         check(lib().phnsw_store_create_pq(full._h, m, ksub, seed, C.byref(h)))
         VectorStore.__init__(self, _handle=h, device=full.device)
-        if table_f16:
-            check(lib().phnsw_pq_set_table_f16(self._h, 1))
-        self.table_f16 = bool(table_f16)
+        mode = self.TABLE_MODES[table_mode] if table_mode is not None else int(table_f16)
+        if mode:
+            check(lib().phnsw_pq_set_table_mode(self._h, mode))
+        self.table_mode = mode
+        self.table_f16 = mode == 1
+
         self.full = full
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().phnsw_pq_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         self.m, self.ksub, self.dsub = a.value, b.value, c.value
+
+    def set_table_mode(self, table_mode):
+        """switch the lookup-table storage; "u8" is search-only (see phnsw_pq_set_table_mode)"""
+        mode = self.TABLE_MODES[table_mode] if isinstance(table_mode, str) else int(table_mode)
+        check(lib().phnsw_pq_set_table_mode(self._h, mode))
+        self.table_mode, self.table_f16 = mode, mode == 1
 
     def codes(self):
         out = np.empty((self.n, self.m), dtype=np.uint8)
@@ -176,7 +188,8 @@ class PqStore(VectorStore):
 class QuantizedHnsw:
     """QuantizedHnsw (pq.rs:120-131, 287-364): quantizer + Hnsw over the codes + full comparator"""
 
-    def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False):
+    def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False,
+                 table_mode=None):
         """QuantizedHnsw::new(number_of_centroids, comparator, bp): per-sub-space codebooks of
         `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes.
 
@@ -187,7 +200,7 @@ class QuantizedHnsw:
         the candidates) never finishes at scale -- in the reference as much as here."""
         m = m or max(4, comparator.dim // 8)
         self.full = comparator
-        self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16)
+        self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16, table_mode)
         vids = np.arange(comparator.n, dtype=np.uint64) if vids is None else vids
         self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters(promote=0))
 

@@ -20,6 +20,44 @@ def make(n, dim, m, ksub, seed=0, metric=0, clustered=False, table_f16=False):
     return rows, full, pq, ocodes, ocb
 
 
+@pytest.mark.parametrize("metric", [0, 2])
+def test_quantised_distance_batch_u8_table(metric):
+    """table mode 2 against a numpy restatement of its definition: 8-bit entries
+    rint((T - min_row) / scale), scale = widest row range / 255, distance = bias + scale * sum"""
+    n, dim, m, ksub = 600, 64, 16, 128
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, metric=metric, table_f16=2)
+    ids = np.arange(n, dtype=np.uint64)
+    q = oracle.synth_rows(2 ** 32, 1, dim)[0, :dim]
+    f = np.float32
+    for qq, got in ((q, pq.compare_vec(ph.Unstored(q), ids)), (None, pq.compare_vec(ph.Stored(5), ids))):
+        T = np.zeros((m, ksub), dtype=np.float32)
+        for j in range(m):
+            sub = qq[j * (dim // m):(j + 1) * (dim // m)] if qq is not None else ocb[j, ocodes[5, j]]
+            for k in range(ksub):
+                acc = f(0)
+                for e in range(dim // m):
+                    if metric == 2:
+                        df = f(sub[e] - ocb[j, k, e])
+                        acc = f(np.float64(df) * np.float64(df) + np.float64(acc))
+                    else:
+                        acc = f(np.float64(sub[e]) * np.float64(ocb[j, k, e]) + np.float64(acc))
+                T[j, k] = acc
+        lo = T.min(axis=1)
+        widest = f(max(f(T[j].max() - lo[j]) for j in range(m)))
+        bias = f(0)
+        for j in range(m):
+            bias = f(bias + lo[j])
+        scale = f(widest / f(255))
+        U = np.rint((T - lo[:, None]) / scale).astype(np.int64)
+        assert U.min() >= 0 and U.max() <= 255
+        exp = np.empty(n, dtype=np.float32)
+        for i in range(n):
+            sm = int(sum(U[j, ocodes[i, j]] for j in range(m)))
+            r = f(bias + f(scale * f(sm)))
+            exp[i] = {0: f((f(1) - r) / f(2)), 2: f(np.sqrt(r))}[metric]
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
 @pytest.mark.parametrize("n,dim,m,ksub", [(2000, 64, 8, 256), (1500, 96, 24, 64), (3000, 768, 96, 256)])
 def test_codebook_and_codes_match_oracle(n, dim, m, ksub):
     rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=3)
@@ -69,14 +107,18 @@ def test_quantised_distance_batch_bit_exact(metric):
     np.testing.assert_array_equal(got_s.view(np.uint32), exp_s.view(np.uint32))
 
 
+# f16 column = the table mode: 0/False f32, 1/True IEEE-half entries, 2 8-bit entries with a per-query scale
 @pytest.mark.parametrize("n,dim,m,ksub,f16", [(2500, 64, 16, 256, False), (1500, 768, 96, 256, False),
-                                              (1500, 768, 96, 256, True), (2000, 64, 16, 128, True)])
+                                              (1500, 768, 96, 256, True), (2000, 64, 16, 128, True),
+                                              (1500, 768, 96, 256, 2), (2500, 64, 16, 256, 2), (1800, 96, 24, 100, 2)])
 def test_pq_index_build_and_search_parity(n, dim, m, ksub, f16):
-    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=1, clustered=True, table_f16=f16)
+    # mode 2 (8-bit entries) is asymmetric, hence search-only: its graph is built in mode 0
+    build_mode = 0 if f16 == 2 else f16
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=1, clustered=True, table_f16=build_mode)
     bp_kw = dict(seed=2, promote=0)
     # oracle: Hnsw::generate over the code rows (QuantizedHnsw::new pq.rs:337-338)
     oix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
-    oix.set_pq(ocodes, ocb, table_f16=f16)
+    oix.set_pq(ocodes, ocb, table_f16=build_mode)
     obp = oracle.default_build_params(**bp_kw)
     vs = oracle.shuffle(np.arange(n), obp.seed)
     sizes = oracle.calculate_partitions(n, obp.order)
@@ -88,6 +130,14 @@ def test_pq_index_build_and_search_parity(n, dim, m, ksub, f16):
     for l in range(oix.layer_count):
         nodes, nb = oix.layer(l)
         np.testing.assert_array_equal(g._layer(l).neighbors, nb, err_msg="layer %d" % l)
+    if f16 == 2:
+        with pytest.raises(ph.PhnswError):  # build entry points refuse the asymmetric mode
+            pq.set_table_mode("u8")
+            ph.Hnsw.generate(pq, np.arange(n), ph.BuildParameters(**bp_kw))
+        oracle.lib().orc_index_set_pq_table_f16(oix.h, 2)
+        gs_, cs_ = g.search_batch(qids=np.arange(50), sp=ph.SearchParameters(32, 32, 2)), oix.search(qids=np.arange(50), sp=(32, 32, 2))
+        np.testing.assert_array_equal(gs_[0], cs_[0])   # Stored queries in the search-only mode
+        np.testing.assert_array_equal(gs_[1].view(np.uint32), cs_[1].view(np.uint32))
     # quantised search, raw query (ADC) -- ids, distances, counters
     q = oracle.synth_clustered_rows(2 ** 32, 200, dim, n_clusters=20)[:, :dim]
     sp = (64, 64, 2)
