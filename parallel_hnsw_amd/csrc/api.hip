@@ -618,6 +618,13 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
       first_big = l;
       break;
     }
+  if (!a.order && knn_mode && nq >= PH_ORDER_MIN) {
+    // knn / threshold_nn: the queries are the bottom layer's nodes first_node .. first_node + nq
+    PhLayerHost &B = mix->layers[a.n_layers - 1];
+    rc = ph_layer_anchor_pos(ix->store, B);
+    if (!rc && first_node + nq <= B.n_nodes) rc = ph_layer_range_order(B, first_node, (uint32_t)nq, &a.order);
+    if (rc) return rc;
+  }
   const bool split = !a.order && !knn_mode && !out_stride && first_big < a.n_layers && nq >= PH_TWO_LAUNCH_MIN &&
                      !getenv("PHNSW_NO_LOCALITY");
   if (!split) return ph_search_launch(ix, ws, a, stream);
