@@ -90,3 +90,32 @@ def test_large_stored_batch_with_exclude(built):
     np.testing.assert_array_equal(two[1].view(np.uint32), one[1].view(np.uint32))
     np.testing.assert_array_equal(two[2], one[2])
     np.testing.assert_array_equal(two[3], one[3])
+
+
+def test_bulk_knn_is_schedule_independent(built):
+    """knn over all 400 000 bottom-layer nodes: cell-ordered launch == plain launch; a slice == oracle"""
+    from parallel_hnsw_amd.hnsw import _p
+    store, h, _ = built
+    k = 3
+
+    def run():
+        ids = np.empty((N, k), dtype=np.uint64)
+        d = np.empty((N, k), dtype=np.float32)
+        ln = np.zeros(N, dtype=np.uint64)
+        ph._lib.check(lib().phnsw_knn(h._h, k, 2, _p(ids), _p(d), _p(ln)))
+        return ids, d, ln
+
+    a = run()
+    with plain_schedule():
+        b = run()
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    np.testing.assert_array_equal(a[2], b[2])
+    ix = oracle.Index(store.read(), dim=DIM, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_BLOCKED64)
+    bottom = h.layers[-1]
+    ix.push_layer(bottom.nodes, bottom.neighbors, bottom.neighborhood_size)
+    ki, kd, kl = ix.knn(k, 2)
+    np.testing.assert_array_equal(a[2], kl)
+    m = kl[:, None] > np.arange(k)[None, :]
+    np.testing.assert_array_equal(a[0][m], ki[m])
+    np.testing.assert_array_equal(a[1][m].view(np.uint32), kd[m].view(np.uint32))
