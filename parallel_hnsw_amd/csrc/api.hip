@@ -568,7 +568,14 @@ static void fill_args(const phnsw_index *ix, const phnsw_search_params *sp, uint
   a.probe_depth = (uint32_t)sp->probe_depth;
 }
 
-static uint32_t default_ovf_cap(uint32_t ef) { return std::max<uint32_t>(8192u, ef * 64u); }
+// spill-list entries per resident wave; PHNSW_OVF_CAP (tests) forces a small list so that the
+// overflow -> rerun paths run
+uint32_t ph_default_ovf_cap(uint32_t ef) {
+  if (const char *e = getenv("PHNSW_OVF_CAP"))
+    if (atoi(e) > 0) return (uint32_t)atoi(e);
+  return std::max<uint32_t>(8192u, ef * 64u);
+}
+static uint32_t default_ovf_cap(uint32_t ef) { return ph_default_ovf_cap(ef); }
 
 static uint64_t g_two_launch_count = 0;  // tests check that the two-launch path really ran
 extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count; }

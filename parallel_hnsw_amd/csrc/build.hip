@@ -537,7 +537,7 @@ static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32
   }
   DevBuf<uint32_t> status;
   PH_TRY(status.alloc(nq));
-  uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+  uint32_t ovf_cap = ph_default_ovf_cap((uint32_t)sp->number_of_candidates);
   for (int attempt = 0; attempt < 3; attempt++) {
     PH_TRY(ph_search_device(ix, nullptr, 0, qids_dev, nq, sp, upto, exclude_dev, out_ids, out_d, out_len, nullptr,
                             status.p, ovf_cap, 0, 0, out_stride, out_hit, 0.f, 0, 0.f, order));
@@ -1118,7 +1118,7 @@ static int discover_hits_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_
   PH_TRY(d.alloc(count));
   PH_TRY(len.alloc(count));
   PH_TRY(status.alloc(count));
-  uint32_t ovf_cap = std::max<uint32_t>(8192u, (uint32_t)sp->number_of_candidates * 64u);
+  uint32_t ovf_cap = ph_default_ovf_cap((uint32_t)sp->number_of_candidates);
   const uint32_t *order = nullptr;
   PH_TRY(ph_layer_range_order(L, first, count, &order));
   for (int attempt = 0; attempt < 3; attempt++) {

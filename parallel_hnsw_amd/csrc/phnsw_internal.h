@@ -155,6 +155,7 @@ struct PhSearchArgs {
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
 };
 
+uint32_t ph_default_ovf_cap(uint32_t ef);
 void ph_layer_free(PhLayerHost &l);
 void ph_pending_free(phnsw_index *ix);
 int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
