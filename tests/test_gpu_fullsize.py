@@ -75,3 +75,25 @@ def test_self_recall_full_size(built):
     assert recall >= 0.9, recall
     assert np.abs(d[ids[:, 0] == qids, 0]).max() < 1e-5
     assert h.stochastic_recall() >= 0.9
+
+
+def test_search_sample_equals_oracle_full_size(built):
+    """the oracle cannot build at this size in test time, but it can search: a sample of queries
+    over the GPU-built 1M x 768 graph must come back bit-identical (ids, distances, counters), in
+    the small-batch path and inside a 40 000-query batch (split, cell-ordered descent)"""
+    import oracle
+    store, h = built
+    rows = store.read()
+    ix = oracle.Index(rows, dim=DIM, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_BLOCKED64)
+    for l in h.layers:
+        ix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    qs = ph.VectorStore.clustered(40_000, DIM, seed=42, first=2 ** 34)
+    q = qs.read()
+    sp = ph.SearchParameters(128, 128, 8)
+    m = 192
+    ci, cd, cl, cs = ix.search(queries=q[:m], sp=(128, 128, 8), stats=True)
+    for got in (h.search_batch(queries=q[:m], sp=sp, stats=True), h.search_batch(queries=q, sp=sp, stats=True)):
+        np.testing.assert_array_equal(got[0][:m], ci)
+        np.testing.assert_array_equal(got[1][:m].view(np.uint32), cd.view(np.uint32))
+        np.testing.assert_array_equal(got[2][:m], cl)
+        np.testing.assert_array_equal(got[3][:m], cs)
