@@ -97,3 +97,40 @@ def test_search_sample_equals_oracle_full_size(built):
         np.testing.assert_array_equal(got[1][:m].view(np.uint32), cd.view(np.uint32))
         np.testing.assert_array_equal(got[2][:m], cl)
         np.testing.assert_array_equal(got[3][:m], cs)
+
+
+def test_link_round_searches_equal_oracle_full_size(built):
+    """the search step of a link round (lib.rs:1107-1117: every node searches the stack with itself
+    excluded, the first neighborhood_size results become proposals) for a slice of bottom-layer and
+    of 83k-layer nodes on the 1M graph: the phase entry point of the ABI against the oracle's"""
+    import ctypes as C
+    import torch
+    import oracle
+    from parallel_hnsw_amd._lib import check, lib
+    store, h = built
+    ix = oracle.Index(store.read(), dim=DIM, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_BLOCKED64)
+    for l in h.layers:
+        ix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    L = oracle.lib()
+    dev = torch.device("cuda", 0)
+    M, count = 24, 96
+    bp = ph.BuildParameters()
+    sp = bp.optimization.search
+    osp = oracle.SearchParams(sp.number_of_candidates, sp.upper_layer_candidate_count, sp.probe_depth)
+    for lft, first in ((h.layer_count() - 1, 617_283), (h.layer_count() - 2, 40_000)):
+        ids = torch.empty((count, M), dtype=torch.int32, device=dev)
+        d = torch.empty((count, M), dtype=torch.float32, device=dev)
+        ln = torch.empty(count, dtype=torch.int32, device=dev)
+        check(lib().phnsw_link_search_device(h._h, lft, C.byref(sp), M, first, count, C.c_void_p(ids.data_ptr()),
+                                             C.c_void_p(d.data_ptr()), C.c_void_p(ln.data_ptr())))
+        torch.cuda.synchronize()
+        oi = np.empty((count, M), dtype=np.uint64)
+        od = np.empty((count, M), dtype=np.float32)
+        ol = np.empty(count, dtype=np.uint64)
+        assert L.orc_link_search(ix.h, lft, osp, M, first, count, oi.ctypes.data_as(C.c_void_p),
+                                 od.ctypes.data_as(C.c_void_p), ol.ctypes.data_as(C.c_void_p), 8) == 0
+        gi = ids.cpu().numpy().astype(np.uint64)
+        gi[gi == 0xFFFFFFFF] = oracle.EMPTY
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+        np.testing.assert_array_equal(ln.cpu().numpy().astype(np.uint64), ol)
