@@ -326,7 +326,9 @@ __global__ void ph_rank_of_cell_kernel(uint32_t *pos, uint32_t n, const uint32_t
 // The store's coarse cells: A anchors (every (n/A)-th row) and their chain ranks, made once.
 static int ph_store_anchors(phnsw_store *s) {
   if (s->anchors) return 0;
-  const uint32_t A = (uint32_t)std::min<uint64_t>(4096u, std::max<uint64_t>(s->n / 16u, 1u)), ld = s->ld;
+  uint32_t amax = 4096u;
+  if (const char *e = getenv("PHNSW_ANCHORS")) amax = atoi(e) >= 64 ? (uint32_t)atoi(e) : amax;  // tuning knob
+  const uint32_t A = (uint32_t)std::min<uint64_t>(amax, std::max<uint64_t>(s->n / 16u, 1u)), ld = s->ld;
   const uint64_t stride = s->n / A;
   float *anchors = nullptr, *gram = nullptr;
   uint32_t *rank = nullptr, *ids = nullptr;
