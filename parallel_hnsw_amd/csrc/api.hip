@@ -499,6 +499,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   ph_workspace_free(ix->ws[1]);
   phnsw_store_destroy(ix->store);
   delete ix;
+  ph_pool_trim();
 }
 
 extern "C" uint32_t phnsw_index_layer_count(const phnsw_index *ix) { return ix ? (uint32_t)ix->layers.size() : 0; }

@@ -35,7 +35,7 @@ struct DevBuf {
   size_t n = 0;
   int alloc(size_t count) {
     n = count;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    hipError_t e = ph_pool_alloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
     if (e != hipSuccess) {
       p = nullptr;
       return ph_hip_fail(e, "hipMalloc (build)", __FILE__, __LINE__);
@@ -43,7 +43,7 @@ struct DevBuf {
     return 0;
   }
   ~DevBuf() {
-    if (p) hipFree(p);
+    if (p) ph_pool_free(p);
   }
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
@@ -1651,7 +1651,9 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
 
 extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
                            phnsw_progress_cb cb, void *user, phnsw_index **out) {
-  return build_impl(s, vids, n, bp, cb, user, out);
+  int rc = build_impl(s, vids, n, bp, cb, user, out);
+  ph_pool_trim();  // scratch of the rounds goes back to the driver
+  return rc;
 }
 
 extern "C" int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,

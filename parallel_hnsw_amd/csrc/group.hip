@@ -41,12 +41,12 @@ int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const 
   void *tmp = nullptr;
   size_t tmp_bytes = 0;
   int rc = 0;
-  hipError_t e = hipMalloc(&keys_in, (size_t)n * 8);
-  if (e == hipSuccess) e = hipMalloc(&keys_out, (size_t)n * 8);
-  if (e == hipSuccess) e = hipMalloc(&vals_in, (size_t)n * 4);
+  hipError_t e = ph_pool_alloc((void **)&keys_in, (size_t)n * 8);
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&keys_out, (size_t)n * 8);
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&vals_in, (size_t)n * 4);
   if (e == hipSuccess)
     e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, gm, (int)n, 0, 64, 0);
-  if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&tmp, std::max<size_t>(tmp_bytes, 16));
   if (e == hipSuccess) {
     uint32_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(ph_group_keys_kernel, dim3(blocks), dim3(256), 0, 0, init_ids, init_d, init_len, K, n, keys_in,
@@ -61,10 +61,10 @@ int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const 
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) rc = ph_hip_fail(e, "partition groups (radix sort)", __FILE__, __LINE__);
-  if (keys_in) hipFree(keys_in);
-  if (keys_out) hipFree(keys_out);
-  if (vals_in) hipFree(vals_in);
-  if (tmp) hipFree(tmp);
+  if (keys_in) ph_pool_free(keys_in);
+  if (keys_out) ph_pool_free(keys_out);
+  if (vals_in) ph_pool_free(vals_in);
+  if (tmp) ph_pool_free(tmp);
   return rc;
 }
 
@@ -86,20 +86,20 @@ int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_ou
   void *tmp = nullptr;
   size_t tmp_bytes = 0;
   int rc = 0;
-  hipError_t e = hipMalloc(&keys_out, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc(&vals_in, (size_t)n * 4);
+  hipError_t e = ph_pool_alloc((void **)&keys_out, (size_t)n * 4);
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&vals_in, (size_t)n * 4);
   if (e == hipSuccess)
     e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, vals_in, order_out, (int)n, 0, 32, st);
-  if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&tmp, std::max<size_t>(tmp_bytes, 16));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(ph_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vals_in, n);
     e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, vals_in, order_out, (int)n, 0, 32, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
   }
   if (e != hipSuccess) rc = ph_hip_fail(e, "query order (radix sort)", __FILE__, __LINE__);
-  if (keys_out) hipFree(keys_out);
-  if (vals_in) hipFree(vals_in);
-  if (tmp) hipFree(tmp);
+  if (keys_out) ph_pool_free(keys_out);
+  if (vals_in) ph_pool_free(vals_in);
+  if (tmp) ph_pool_free(tmp);
   return rc;
 }
 

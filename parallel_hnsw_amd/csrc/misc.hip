@@ -176,3 +176,76 @@ int ph_count_nan(const float *rows, uint64_t n_floats, uint32_t *out_count_dev, 
   PH_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- scratch pool (see phnsw_internal.h) ----
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+std::mutex g_pool_mutex;
+std::multimap<size_t, void *> g_pool_free;          // size class -> cached block
+std::unordered_map<void *, size_t> g_pool_size;     // every live or cached block -> its size class
+size_t g_pool_cached = 0;
+const size_t POOL_CACHE_LIMIT = 24ull << 30;
+size_t cb0(size_t c) { return c & ((1ull << 56) - 1); }
+size_t pool_class(size_t bytes) {
+  size_t c = 4096;
+  while (c < bytes) c += c < (1ull << 20) ? c : std::max<size_t>(c / 4, 1);  // x2 up to 1 MiB, then x1.25
+  return c;
+}
+}  // namespace
+
+hipError_t ph_pool_alloc(void **p, size_t bytes) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  // blocks are cached per device: the size class carries the device in its top byte
+  const size_t c = pool_class(std::max<size_t>(bytes, 1)) | ((size_t)dev << 56);
+  {
+    std::lock_guard<std::mutex> g(g_pool_mutex);
+    auto it = g_pool_free.find(c);
+    if (it != g_pool_free.end()) {
+      *p = it->second;
+      g_pool_free.erase(it);
+      g_pool_cached -= cb0(c);
+      return hipSuccess;
+    }
+  }
+  const size_t cb = c & ((1ull << 56) - 1);
+  hipError_t e = hipMalloc(p, cb);
+  if (e != hipSuccess) {  // memory held by the cache may be what is missing
+    ph_pool_trim();
+    e = hipMalloc(p, cb);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> g(g_pool_mutex);
+    g_pool_size[*p] = c;
+  }
+  return e;
+}
+
+void ph_pool_free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> g(g_pool_mutex);
+  auto it = g_pool_size.find(p);
+  if (it == g_pool_size.end()) {
+    hipFree(p);
+    return;
+  }
+  if (g_pool_cached + cb0(it->second) > POOL_CACHE_LIMIT) {
+    g_pool_size.erase(it);
+    hipFree(p);
+    return;
+  }
+  g_pool_free.emplace(it->second, p);
+  g_pool_cached += cb0(it->second);
+}
+
+void ph_pool_trim(void) {
+  std::lock_guard<std::mutex> g(g_pool_mutex);
+  for (auto &kv : g_pool_free) {
+    g_pool_size.erase(kv.second);
+    hipFree(kv.second);
+  }
+  g_pool_free.clear();
+  g_pool_cached = 0;
+}

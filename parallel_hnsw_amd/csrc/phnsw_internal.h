@@ -156,6 +156,12 @@ struct PhSearchArgs {
 };
 
 uint32_t ph_default_ovf_cap(uint32_t ef);
+// scratch allocator of the build path (misc.hip): hipMalloc / hipFree cost ~0.1 ms and a device
+// sync each, a build issues thousands of them; freed blocks are kept by size class and handed
+// out again (everything on the path runs on the null stream, so reuse is stream ordered)
+hipError_t ph_pool_alloc(void **p, size_t bytes);
+void ph_pool_free(void *p);
+void ph_pool_trim(void);  // give everything cached back to the driver
 void ph_layer_free(PhLayerHost &l);
 void ph_pending_free(phnsw_index *ix);
 int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
