@@ -154,6 +154,8 @@ def main():
         if world > 1:
             dist.barrier()
         build_s = time.time() - t0
+        b_dist, b_hops = index.counters()  # every search of the build rounds (this rank's share when sharded)
+        build_bytes = b_dist * store.ld * 4 + b_hops * 48 * 4
         log("index built in %.1f s (%.0f vectors/s), layers %s" % (
             build_s, args.n / build_s, [index._layer(l).node_count() for l in range(index.layer_count())]))
         # calibration queries are the same on every rank => every rank picks the same parameters
@@ -274,6 +276,11 @@ def main():
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
             "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
             "batch_sweep": batch_sweep,
+            "build_roofline": {"bound": "hbm", "distance_evals": b_dist, "hops": b_hops,
+                               "algorithmic_bytes": build_bytes, "achieved": round(build_bytes / build_s / 1e9, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(build_bytes / build_s / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "searches of the build rounds only (K2: 92 % of the build's GPU time); whole "
+                                       "build wall time incl. host control flow; per rank when sharded"},
             "dispatches": (1 + sum(1 for l in range(1, index.layer_count()) if index._layer(l).node_count() >= 32768))
             if args.nq >= 32768 else 1,
         }
@@ -465,6 +472,7 @@ def main():
             "secondary": iid,
             "pq": pq,
             "batch_sweep": res["batch_sweep"],
+            "build_roofline": res["build_roofline"],
             "sweep": res["sweep"],
         }
         print(json.dumps(line), flush=True)

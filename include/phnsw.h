@@ -190,6 +190,10 @@ int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, u
                               uint32_t *out_stats_dev, uint32_t *status_dev, void *stream);
 /* timing of the last phnsw_search_batch_device launch on this index measured with HIP
  * events on its stream: kernel milliseconds */
+/* running totals of distance evaluations and hops over every search launched on the index since
+ * its creation (build rounds included; the reference's SearchStats per query, search.rs:93-99,
+ * summed): the build's algorithmic bytes are n_dist * row bytes + n_hops * neighbour-row bytes */
+int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uint64_t *n_hops);
 int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
 
 /* ---- phase API: the per-round pieces of phnsw_generate_layer / phnsw_link_layer /

@@ -497,6 +497,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   ph_pending_free(ix);
   ph_workspace_free(ix->ws[0]);
   ph_workspace_free(ix->ws[1]);
+  if (ix->totals) hipFree(ix->totals);
   phnsw_store_destroy(ix->store);
   delete ix;
   ph_pool_trim();
@@ -609,6 +610,11 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.cap_max = knn_mode == 2 ? out_stride : 0;
   a.order = (ix->dbg_order && ix->dbg_order_n == nq) ? ix->dbg_order : order;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
+  if (!mix->totals) {
+    PH_HIP(hipMalloc(&mix->totals, 16));
+    PH_HIP(hipMemset(mix->totals, 0, 16));
+  }
+  a.totals = mix->totals;
   PhWorkspace &ws = mix->ws[mix->ws_next & 1];
   mix->ws_last = mix->ws_next & 1;
   mix->ws_next++;
@@ -685,6 +691,21 @@ extern "C" int phnsw_debug_layer_pos(phnsw_index *ix, uint32_t lft, uint32_t *ou
 extern "C" int phnsw_debug_set_order(phnsw_index *ix, const uint32_t *order_dev, uint64_t n) {
   ix->dbg_order = order_dev;
   ix->dbg_order_n = n;
+  return 0;
+}
+
+// distance evaluations and hops of every search launched on this index since it was created --
+// build rounds included: the basis of the build's algorithmic bytes
+extern "C" int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uint64_t *n_hops) {
+  if (!ix) return PHNSW_E_INVALID;
+  unsigned long long h[2] = {0, 0};
+  if (ix->totals) {
+    PH_HIP(hipSetDevice(ix->store->device));
+    PH_HIP(hipDeviceSynchronize());
+    PH_HIP(hipMemcpy(h, ix->totals, 16, hipMemcpyDeviceToHost));
+  }
+  if (n_dist) *n_dist = h[0];
+  if (n_hops) *n_hops = h[1];
   return 0;
 }
 

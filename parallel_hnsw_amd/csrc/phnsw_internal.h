@@ -112,6 +112,7 @@ struct phnsw_index {
   PhWorkspace ws[2];
   uint32_t ws_next = 0, ws_last = 0;
   float last_kernel_ms = 0.f;
+  unsigned long long *totals = nullptr;  // device [2]: distance evaluations, hops of every launch on this index
   const uint32_t *dbg_order = nullptr;  // experiment hook
   uint64_t dbg_order_n = 0;
 };
@@ -145,6 +146,7 @@ struct PhSearchArgs {
   uint32_t cap_max;     // threshold_nn: largest queue capacity the launch must support (0 = ef)
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
+  unsigned long long *totals;   // nullable: [2] running sums of distance evaluations / hops (all launches)
   void *pq_tables;              // PQ store: per-wave lookup-table slots in global memory (DistPQG)
   uint32_t pq_table_bytes;      // bytes per slot
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip

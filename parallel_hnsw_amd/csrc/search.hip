@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       dist.prepare_stored(a.dist, qvec, dist_lds, lane);
     const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
     uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
+    uint32_t n_dist0 = 0, n_hops0 = 0;  // counters a split descent brought in from its earlier launches
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
 
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         n_dist = a.out_stats[2 * (uint64_t)q];
         n_hops = a.out_stats[2 * (uint64_t)q + 1];
       }
+      n_dist0 = n_dist;
+      n_hops0 = n_hops;
     } else if (!a.knn_mode) {
       // entry_vector + distance_from_entry  search.rs:101-111
       uint32_t entry = a.layers[0].nodes[0];
@@ -528,6 +531,10 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         if (nid < KL.n_nodes) key = a.key_pos ? a.key_pos[nid] : nid;
       }
       a.out_key[q] = key;
+    }
+    if (lane == 0 && a.totals) {
+      atomicAdd(&a.totals[0], (unsigned long long)(n_dist - n_dist0));
+      atomicAdd(&a.totals[1], (unsigned long long)(n_hops - n_hops0));
     }
     if (lane == 0) {
       a.out_len[q] = clen;

@@ -439,6 +439,12 @@ class Hnsw:
         check(lib().phnsw_index_build_params(h, C.byref(bp)))
         return cls(store, h, bp)
 
+    def counters(self):
+        """(distance evaluations, hops) of every search launched on this index, build rounds included"""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().phnsw_index_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def kernel_ms(self):
         ms = C.c_float()
         check(lib().phnsw_last_search_kernel_ms(self._h, C.byref(ms)))

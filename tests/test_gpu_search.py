@@ -227,3 +227,16 @@ def test_bruteforce_mfma_exact(n, dim, metric, k):
     np.testing.assert_allclose(gd, sd, rtol=1e-5, atol=1e-6)
     with pytest.raises(ph.PhnswError):
         ph.VectorStore(rows[:, :dim], metric=2).bruteforce_topk(q, k)  # L2 is not a GEMM here
+
+
+def test_index_counters_sum_the_per_query_stats():
+    """phnsw_index_counters = the reference's per-query SearchStats (search.rs:93-99) summed over
+    every launch on the index"""
+    rows, ix = build_oracle_index(3000, 32, seed=4)
+    store, g = to_gpu(rows, 32, ix, oracle.METRIC_COSINE_HALF)
+    assert g.counters() == (0, 0)
+    q = oracle.synth_rows(2 ** 32, 500, 32)[:, :32]
+    _, _, _, st = g.search_batch(queries=q, sp=ph.SearchParameters(24, 24, 2), stats=True)
+    assert g.counters() == (int(st[:, 0].sum()), int(st[:, 1].sum()))
+    _, _, _, st2 = g.search_batch(qids=np.arange(100), sp=ph.SearchParameters(8, 8, 2), stats=True)
+    assert g.counters() == (int(st[:, 0].sum() + st2[:, 0].sum()), int(st[:, 1].sum() + st2[:, 1].sum()))
