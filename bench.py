@@ -168,7 +168,7 @@ def main():
             # (number_of_candidates, upper_layer_candidate_count, probe_depth): the reference's three
             # SearchParameters (parameters.rs:3-14); its default keeps the upper count equal to the
             # bottom one, a narrower upper queue is the classic HNSW setting
-            base = [(64, 2), (128, 2), (128, 4), (128, 8), (200, 4), (300, 2), (300, 4), (200, 8), (300, 8),
+            base = [(64, 2), (128, 2), (128, 4), (96, 8), (104, 8), (128, 5), (96, 16), (112, 8), (128, 6), (128, 8), (200, 4), (300, 2), (300, 4), (200, 8), (300, 8),
                     (128, 16), (300, 16), (512, 16), (512, 32), (1024, 64)]
             # (measured: a narrower upper count does not help -- the reference searches every layer with a
             # queue of number_of_candidates and only truncates its output, lib.rs:258-276)
@@ -186,7 +186,8 @@ def main():
             log("sweep ef=%d upper=%d pd=%d recall@10=%.4f  %.0f q/s" % (ef, up, pd, rec, qps))
             # fastest setting that meets the target; settings within 3 % count as equal and the
             # earlier one is kept, so that run-to-run noise does not flip the choice
-            if rec >= args.target_recall and (chosen is None or qps > 1.03 * chosen[3]):
+            # (0.003 of margin on the calibration set, so that the timed batch -- other queries -- meets it too)
+            if rec >= args.target_recall + 0.003 and (chosen is None or qps > 1.03 * chosen[3]):
                 chosen = (ef, up, pd, qps, rec)
         met = chosen is not None
         if not met:  # report honestly at the BASELINE configuration ef_search=128

@@ -6,7 +6,7 @@ set -e
 ROUND=${1:-r01}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$ROUND
-FLAGS="--skip-iid --skip-pq --cpu-seconds 0 --ef 128 --probe-depth 8"
+FLAGS="--skip-iid --skip-pq --cpu-seconds 0 --ef 104 --probe-depth 8"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py --steps 20 $FLAGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
