@@ -236,12 +236,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        # per-launch kernel time from HIP events on the launch stream (separate, untimed pass so
-        # the event reads do not serialise the timed region)
-        for _ in range(min(args.steps, 10)):
-            run.launch(sp)
-            torch.cuda.synchronize()
-            kms.append(index.kernel_ms())
         # latency side of the same path (batch sizes 1, 64, 1 024, 10 000): one
         # isolated launch per measurement, the first nq queries of the timed batch
         batch_sweep = []
@@ -257,9 +251,13 @@ def main():
                     torch.cuda.synchronize()
                     ms.append(index.kernel_ms())
                 batch_sweep.append({"queries": b, "kernel_ms": round(min(ms), 3), "queries_per_s": round(b / min(ms) * 1e3)})
-            run.launch(sp)  # restore the full batch's results for the recall / counters below
-            torch.cuda.synchronize()
             log("batch sweep: " + ", ".join("%d: %.2f ms" % (x["queries"], x["kernel_ms"]) for x in batch_sweep))
+        # per-launch kernel time from HIP events on the launch stream (separate, untimed pass so
+        # the event reads do not serialise the timed region)
+        for _ in range(min(args.steps, 10)):
+            run.launch(sp)
+            torch.cuda.synchronize()
+            kms.append(index.kernel_ms())
         if world > 1:
             t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
