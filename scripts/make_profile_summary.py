@@ -61,8 +61,9 @@ def main():
             continue
         rows = [r for r in rows if r["Counter_Name"] == key]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-        lastp = rows[-isolated * per:]
-        vals = [sum(float(r["Counter_Value"]) for r in lastp[i * per:(i + 1) * per]) for i in range(isolated)]
+        iso_p = 5  # the PMC passes run bench.py with --steps 5: five isolated launches close the run
+        lastp = rows[-iso_p * per:]
+        vals = [sum(float(r["Counter_Value"]) for r in lastp[i * per:(i + 1) * per]) for i in range(iso_p)]
         pm[key + "_KB_per_launch"] = sum(vals) / len(vals)
     if "FETCH_SIZE_KB_per_launch" in pm:
         fetch = pm["FETCH_SIZE_KB_per_launch"] * 1024 * 2  # gfx950 correction, see below
