@@ -639,7 +639,10 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
     if (!rc && first_node + nq <= B.n_nodes) rc = ph_layer_range_order(B, first_node, (uint32_t)nq, &a.order);
     if (rc) return rc;
   }
-  const bool split = !a.order && !knn_mode && !out_stride && first_big < a.n_layers && nq >= PH_TWO_LAUNCH_MIN &&
+  // (not for PQ stores: their searches are not bound by where rows come from, and every launch
+  // would build the per-query table again)
+  const bool split = ix->store->rows && !a.order && !knn_mode && !out_stride && first_big < a.n_layers &&
+                     nq >= PH_TWO_LAUNCH_MIN &&
                      !getenv("PHNSW_NO_LOCALITY");
   if (!split) return ph_search_launch(ix, ws, a, stream);
   g_two_launch_count++;
