@@ -119,3 +119,21 @@ def test_bulk_knn_is_schedule_independent(built):
     m = kl[:, None] > np.arange(k)[None, :]
     np.testing.assert_array_equal(a[0][m], ki[m])
     np.testing.assert_array_equal(a[1][m].view(np.uint32), kd[m].view(np.uint32))
+
+
+def test_loaded_index_gets_its_cells_lazily(built, tmp_path):
+    """an index that was not built here (deserialised) has no cells; the first large batch makes them"""
+    store, h, _ = built
+    h.serialize(tmp_path / "ix")
+    g = ph.Hnsw.deserialize(tmp_path / "ix", store)
+    q = ph.VectorStore.clustered(NQ, DIM, seed=42, first=2 ** 35, n_clusters=400).read()
+    sp = ph.SearchParameters(24, 24, 2)
+    before = two_launch_count()
+    a = g.search_batch(queries=q, sp=sp, stats=True)
+    assert two_launch_count() == before + 1
+    b = h.search_batch(queries=q, sp=sp, stats=True)
+    with plain_schedule():
+        c = g.search_batch(queries=q, sp=sp, stats=True)
+    for x, y, z in zip(a, b, c):
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, z)
