@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -579,8 +580,8 @@ uint32_t ph_default_ovf_cap(uint32_t ef) {
 }
 static uint32_t default_ovf_cap(uint32_t ef) { return ph_default_ovf_cap(ef); }
 
-static uint64_t g_two_launch_count = 0;  // tests check that the two-launch path really ran
-extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count; }
+static std::atomic<uint64_t> g_two_launch_count{0};  // tests check that the split path really ran
+extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count.load(); }
 
 // enqueue one search launch; caller owns all device buffers
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
