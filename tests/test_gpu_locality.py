@@ -137,3 +137,23 @@ def test_loaded_index_gets_its_cells_lazily(built, tmp_path):
     for x, y, z in zip(a, b, c):
         np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(x, z)
+
+
+@pytest.mark.parametrize("n,dim,metric", [(80_000, 100, 0), (70_000, 1536, 1), (90_000, 36, 2)])
+def test_schedule_independence_other_shapes(n, dim, metric):
+    """row length not a multiple of 64 floats, the widest supported rows, and the L2 metric (for which
+    no cells are made: the GEMM behind them scores dot products)"""
+    store = ph.VectorStore.synthetic(n, dim, seed=7, metric=metric)
+    bp = ph.BuildParameters(max_link_rounds=1, seed=3)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), bp)
+    q = ph.VectorStore.synthetic(33_000, dim, seed=7, first=2 ** 33).read()
+    sp = ph.SearchParameters(16, 16, 2)
+    a = h.search_batch(queries=q, sp=sp, stats=True)
+    with plain_schedule():
+        h2 = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), bp)
+        b = h.search_batch(queries=q, sp=sp, stats=True)
+    layers_equal(h, h2)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
