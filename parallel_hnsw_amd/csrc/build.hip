@@ -681,6 +681,7 @@ static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &no
 // phases (parallel_hnsw_amd/sharded.py); the single-GPU entry point runs the same phases
 // over the whole range.
 
+int ph_sort_u32_host(uint32_t *keys, uint32_t n);  // group.hip
 int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const uint32_t *init_len, uint32_t K,
                            uint32_t n, uint32_t *gm, uint32_t *gstart, uint32_t *gsize);  // group.hip
 
@@ -736,6 +737,7 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
   }
   pending_drop(ix);
   uint32_t n = (uint32_t)n64, W = (uint32_t)W64;
+  PhTimer tb(" layer_begin", n);
   std::vector<uint32_t> nodes(n);
   for (uint32_t i = 0; i < n; i++) {
     if (vids[i] >= s->n) {
@@ -744,16 +746,25 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
     }
     nodes[i] = (uint32_t)vids[i];
   }
-  std::sort(nodes.begin(), nodes.end());  // vs.sort()  lib.rs:685
+  if (!std::is_sorted(nodes.begin(), nodes.end())) {  // vs.sort()  lib.rs:685
+    if (n >= 65536)
+      PH_TRY(ph_sort_u32_host(nodes.data(), n));
+    else
+      std::sort(nodes.begin(), nodes.end());
+  }
   for (uint32_t i = 1; i < n; i++)
     if (nodes[i] == nodes[i - 1]) {
       ph_set_error("generate_layer: duplicate VectorId %u", nodes[i]);
       return PHNSW_E_INVALID;
     }
-  PhTimer tb(" layer_begin", n);
   PhPendingLayer *P = new PhPendingLayer();
-  int rc = ph_layer_upload(ix, nodes.data(), nullptr, n, W, &P->L);  // rows start empty
+  int rc;
+  {
+    PhTimer tu("  layer arrays (alloc + fill)", n);
+    rc = ph_layer_upload(ix, nodes.data(), nullptr, n, W, &P->L);  // rows start empty
+  }
   if (!rc) {
+    PhTimer tu("  nbr_dist alloc", n);
     hipError_t e = hipMalloc(&P->L.nbr_dist, (size_t)n * W * 4);
     if (e != hipSuccess) rc = ph_hip_fail(e, "nbr_dist alloc", __FILE__, __LINE__);
   }
@@ -762,7 +773,10 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
     delete P;
     return rc;
   }
-  if (!rc) rc = ph_layer_anchor_pos(ix->store, P->L);  // locality schedule of the build rounds (group.hip)
+  if (!rc) {
+    PhTimer ta("  layer cells (anchor GEMM)", n);
+    rc = ph_layer_anchor_pos(ix->store, P->L);  // locality schedule of the build rounds (bruteforce.hip)
+  }
   if (rc) {
     ph_layer_free(P->L);
     delete P;

@@ -103,6 +103,27 @@ int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_ou
   return rc;
 }
 
+// ascending sort of host u32 keys through the device (the node list of a big layer arrives in the
+// shuffled order of Hnsw::generate, lib.rs:832-833: 47 ms with std::sort at 1M, 2 ms this way)
+int ph_sort_u32_host(uint32_t *keys, uint32_t n) {
+  uint32_t *in = nullptr, *out = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = 0;
+  hipError_t e = ph_pool_alloc((void **)&in, (size_t)n * 4);
+  if (e == hipSuccess) e = ph_pool_alloc((void **)&out, (size_t)n * 4);
+  if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, in, out, (int)n, 0, 32, (hipStream_t)0);
+  if (e == hipSuccess) e = ph_pool_alloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) e = hipMemcpy(in, keys, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, in, out, (int)n, 0, 32, (hipStream_t)0);
+  if (e == hipSuccess) e = hipMemcpy(keys, out, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = ph_hip_fail(e, "node list sort", __FILE__, __LINE__);
+  if (in) ph_pool_free(in);
+  if (out) ph_pool_free(out);
+  if (tmp) ph_pool_free(tmp);
+  return rc;
+}
+
 // ---- per-workspace argsort of the queries' locality keys, fully asynchronous on `stream`
 // (buffers grow only when a larger batch arrives)
 void ph_workspace_order_free(PhWorkspace &ws) {
