@@ -27,6 +27,10 @@
 
 #include "phnsw_device.h"
 
+// group.hip (rocPRIM sort / scan)
+int ph_sort_u32_host(uint32_t *keys, uint32_t n);
+int ph_exclusive_scan_u32(const uint32_t *cnt, uint32_t n_plus_1, uint32_t *start, hipStream_t st);
+
 // ------------------------------------------------------------------ small helpers
 
 template <typename T>
@@ -286,30 +290,6 @@ __global__ void ph_count_targets_kernel(const uint32_t *tgt, uint64_t nslots, ui
   }
 }
 
-// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; one block
-__global__ __launch_bounds__(1024) void ph_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *start) {
-  __shared__ uint32_t part[1024];
-  uint32_t t = threadIdx.x;
-  uint64_t chunk = ((uint64_t)n + 1023) / 1024;
-  uint64_t lo = std::min<uint64_t>(t * chunk, n), hi = std::min<uint64_t>(lo + chunk, n);
-  uint32_t s = 0;
-  for (uint64_t i = lo; i < hi; i++) s += cnt[i];
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = t ? part[t - 1] : 0;
-  for (uint64_t i = lo; i < hi; i++) {
-    start[i] = run;
-    run += cnt[i];
-  }
-  if (t == 1023) start[n] = part[1023];
-}
-
 __global__ void ph_fill_targets_kernel(const uint32_t *tgt, const float *d, uint64_t nslots, uint32_t S, uint32_t n,
                                        const uint32_t *start, uint32_t *cursor, uint32_t *inc_src, float *inc_d) {
   for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < nslots; x += (uint64_t)gridDim.x * blockDim.x) {
@@ -499,7 +479,7 @@ static int apply_proposals(PhLayerHost &L, const uint32_t *tgt, const float *d, 
   PH_HIP(hipMemsetAsync(added.p, 0, 8, 0));
   uint32_t blocks = (uint32_t)std::min<uint64_t>((nslots + 255) / 256, 8192);
   hipLaunchKernelGGL(ph_count_targets_kernel, dim3(blocks), dim3(256), 0, 0, tgt, nslots, n, cnt.p);
-  hipLaunchKernelGGL(ph_scan_kernel, dim3(1), dim3(1024), 0, 0, cnt.p, n, start.p);
+  PH_TRY(ph_exclusive_scan_u32(cnt.p, n + 1, start.p, 0));  // cnt[n] == 0, so start[n] = total
   PH_HIP(hipGetLastError());
   uint32_t total = 0;
   PH_HIP(hipMemcpy(&total, start.p + n, 4, hipMemcpyDeviceToHost));
@@ -681,7 +661,6 @@ static int generate_first_layer(phnsw_index *ix, const std::vector<uint32_t> &no
 // phases (parallel_hnsw_amd/sharded.py); the single-GPU entry point runs the same phases
 // over the whole range.
 
-int ph_sort_u32_host(uint32_t *keys, uint32_t n);  // group.hip
 int ph_build_groups_device(const uint32_t *init_ids, const float *init_d, const uint32_t *init_len, uint32_t K,
                            uint32_t n, uint32_t *gm, uint32_t *gstart, uint32_t *gsize);  // group.hip
 

@@ -103,6 +103,18 @@ int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_ou
   return rc;
 }
 
+// start[0..n] = exclusive prefix sums of cnt[0..n] (cnt[n] must be 0, so start[n] = total); async on `st`
+int ph_exclusive_scan_u32(const uint32_t *cnt, uint32_t n_plus_1, uint32_t *start, hipStream_t st) {
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, start, (int)n_plus_1, st);
+  if (e == hipSuccess) e = ph_pool_alloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, start, (int)n_plus_1, st);
+  if (tmp) ph_pool_free(tmp);  // same stream: the next user is ordered behind the scan
+  if (e != hipSuccess) return ph_hip_fail(e, "prefix sum", __FILE__, __LINE__);
+  return 0;
+}
+
 // ascending sort of host u32 keys through the device (the node list of a big layer arrives in the
 // shuffled order of Hnsw::generate, lib.rs:832-833: 47 ms with std::sort at 1M, 2 ms this way)
 int ph_sort_u32_host(uint32_t *keys, uint32_t n) {
