@@ -450,7 +450,7 @@ def main():
             "hops_per_query": round(res["n_hops_per_query"], 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         # measured HBM bytes (PMC pass) over the same launch time
+                         # measured bytes on the L2's memory side (PMC pass: HBM + Infinity Cache) over the same launch time
                          "traffic_gbs": round(traffic / (res["kernel_ms"] * 1e-3) / 1e9, 1) if traffic else None,
                          "traffic_frac": round(traffic / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                          if traffic else None,
@@ -461,7 +461,7 @@ def main():
                          "dispatches_per_launch": res["dispatches"],
                          "note": "achieved = algorithmic bytes / time; it can exceed the HBM peak because "
                                  "neighbouring queries are scheduled together and share rows in L2 / the Infinity "
-                                 "Cache (traffic = measured HBM bytes)",
+                                 "Cache (traffic = bytes measured on the L2's memory side: FETCH_SIZE x 2 + WRITE_SIZE)",
                          # the timed region pipelines launches on two streams; per-launch durations are
                          # measured on isolated launches (above); this is the steady-state rate
                          "achieved_pipelined": round(res["alg_bytes"] * args.steps / res["elapsed"] / 1e9, 1)},
