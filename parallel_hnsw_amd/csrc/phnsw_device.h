@@ -148,7 +148,10 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
                                                  bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
                                                  uint32_t lane) {
   // 4 rows in flight per wave (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster)
-  constexpr int U = 4;
+#ifndef PH_ROWS_IN_FLIGHT
+#define PH_ROWS_IN_FLIGHT 4
+#endif
+  constexpr int U = PH_ROWS_IN_FLIGHT;
   float myd = 0.f;
   uint64_t rem = mask;
   while (rem) {
