@@ -89,6 +89,7 @@ CASES = [
     dict(n=1501, dim=24, kw=dict(seed=1)),   # odd size: ranges of unequal length
     # short work lists stay whole on every rank (no collective), the bottom layer is split
     dict(n=1500, dim=16, kw=dict(seed=2), shard_min=400),
+    dict(n=1000, dim=16, kw=dict(seed=4), world=3),   # three ranks: 334 + 334 + 332
     # duplicate-heavy data: rows cannot hold every copy, nodes stay unreachable, promotion
     # (lib.rs:1273-1427) extends and re-tops the upper layers while the build is sharded
     dict(n=1200, dim=16, dup=40, kw=dict(order=6, neighborhood_size=4, zero_layer_neighborhood_size=8, seed=1),
@@ -137,7 +138,8 @@ def _worker(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d%s" % (c["n"], "-min%d" % c["shard_min"] if "shard_min" in c else ""))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d%s%s" % (c["n"], "-min%d" % c["shard_min"] if "shard_min" in c else "",
+                                                                   "-w%d" % c["world"] if "world" in c else ""))
 def test_sharded_build_equals_single_process(case, tmp_path):
     import torch.multiprocessing as mp
     import oracle
@@ -145,14 +147,15 @@ def test_sharded_build_equals_single_process(case, tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    world = case.get("world", 2)
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     rows = _case_rows(case)
     ref = oracle.Index.generate(rows, np.arange(case["n"]), _case_bp(case),
                                 dim=case["dim"], sum_mode=oracle.SUM_BLOCKED64, threads=4)
     if case.get("dup"):
         assert ref.layer_count > len(oracle.calculate_partitions(case["n"], case["kw"]["order"])) or \
             ref.layer(ref.layer_count - 2)[0].shape[0] > case["n"] // case["kw"]["order"]  # promotion happened
-    for rank in range(2):
+    for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert int(z["count"]) == ref.layer_count
         assert int(z["gathered"]) > 0
