@@ -13,7 +13,7 @@ t = time.time(); qh = ph.QuantizedHnsw(256, full, ph.BuildParameters(promote=0),
 print("pq create+build s", time.time() - t, flush=True)
 if len(sys.argv) > 2 and sys.argv[2] == 'u8':  # graph built with the f32 table, searched with 8-bit entries
     from parallel_hnsw_amd._lib import lib, check
-    check(lib().phnsw_pq_set_table_f16(qh.store._h, 2))
+    qh.store.set_table_mode("u8")
 qs = ph.VectorStore.clustered(10000, dim, first=2 ** 32)
 class D:
     def __init__(s, p, shape): s.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (p, False), "version": 2, "strides": None}
