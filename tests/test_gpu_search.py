@@ -240,3 +240,29 @@ def test_index_counters_sum_the_per_query_stats():
     assert g.counters() == (int(st[:, 0].sum()), int(st[:, 1].sum()))
     _, _, _, st2 = g.search_batch(qids=np.arange(100), sp=ph.SearchParameters(8, 8, 2), stats=True)
     assert g.counters() == (int(st[:, 0].sum() + st2[:, 0].sum()), int(st[:, 1].sum() + st2[:, 1].sum()))
+
+
+def test_concurrent_host_threads_share_an_index():
+    """search(&self) is re-entrant in the reference (Rayon calls it from many threads, lib.rs:1107-1117);
+    here concurrent callers share the index's two workspaces behind a mutex"""
+    import threading
+    rows, ix = build_oracle_index(4000, 48, seed=9)
+    store, g = to_gpu(rows, 48, ix, oracle.METRIC_COSINE_HALF)
+    qs = [oracle.synth_rows(2 ** 32 + 1000 * t, 300, 48)[:, :48] for t in range(4)]
+    sp = ph.SearchParameters(32, 32, 2)
+    want = [g.search_batch(queries=q, sp=sp, stats=True) for q in qs]
+    got = [[None] * 3 for _ in range(4)]
+
+    def work(t):
+        for r in range(3):
+            got[t][r] = g.search_batch(queries=qs[t], sp=sp, stats=True)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for t in range(4):
+        for r in range(3):
+            for a, b in zip(got[t][r], want[t]):
+                np.testing.assert_array_equal(a, b)
