@@ -22,7 +22,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, lib
 from .hnsw import BuildParameters, Hnsw
 
