@@ -146,6 +146,9 @@ int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_pro
 /* Hnsw::improve_neighbors_upto  src/lib.rs:1515-1544 ; last_recall NaN = None */
 int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
                                  float last_recall, float *out_recall);
+/* Hnsw::extend_layer  src/lib.rs:1039-1068: vids join the layer with empty neighbourhoods, NodeIds
+ * are renumbered (generate_node_maps :1767-1812); inserting a vector twice is PHNSW_E_INVALID */
+int phnsw_extend_layer(phnsw_index *ix, uint32_t layer_from_top, const uint64_t *vids, uint64_t n);
 /* Hnsw::promote_at_layer  src/lib.rs:1273-1427 ; *out_promoted = the bool it returns */
 int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,
                            int *out_promoted);

@@ -63,6 +63,7 @@ SYMBOLS = {
     "phnsw_link_layer": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, C.POINTER(_u64)]),
     "phnsw_improve_index": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, C.POINTER(_f32)]),
     "phnsw_improve_neighbors_upto": (_i32, [_vp, _u32, C.POINTER(BuildParams), _f32, C.POINTER(_f32)]),
+    "phnsw_extend_layer": (_i32, [_vp, _u32, _vp, _u64]),
     "phnsw_promote_at_layer": (_i32, [_vp, _u32, C.POINTER(BuildParams), C.POINTER(_i32)]),
     "phnsw_discover_unreachable": (_i32, [_vp, _u32, C.POINTER(SearchParams), _vp, C.POINTER(_u64)]),
     "phnsw_stochastic_recall_at": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), C.POINTER(_f32)]),

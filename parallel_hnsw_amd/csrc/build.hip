@@ -1649,6 +1649,30 @@ extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, con
   return rc;
 }
 
+// Hnsw::extend_layer  src/lib.rs:1039-1068: the vectors join the layer with empty rows, old rows
+// are renumbered; a vector that is already in the layer is an error (the reference panics, :1797)
+extern "C" int phnsw_extend_layer(phnsw_index *ix, uint32_t layer_from_top, const uint64_t *vids, uint64_t n) {
+  PH_TRY(enter(ix));
+  if (layer_from_top >= ix->layers.size() || (!vids && n)) {
+    ph_set_error("extend_layer: layer %u out of range", layer_from_top);
+    return PHNSW_E_INVALID;
+  }
+  std::vector<uint32_t> v(n);
+  for (uint64_t i = 0; i < n; i++) {
+    if (vids[i] >= ix->store->n) {
+      ph_set_error("extend_layer: VectorId %llu outside the store", (unsigned long long)vids[i]);
+      return PHNSW_E_INVALID;
+    }
+    v[i] = (uint32_t)vids[i];
+  }
+  std::sort(v.begin(), v.end());
+  if (std::adjacent_find(v.begin(), v.end()) != v.end()) {
+    ph_set_error("extend_layer: duplicate VectorId in the new vectors");
+    return PHNSW_E_INVALID;
+  }
+  return extend_layer_impl(ix, layer_from_top, v);
+}
+
 extern "C" int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,
                                       int *out_promoted) {
   PH_TRY(enter(ix));

@@ -304,6 +304,11 @@ class Hnsw:
                                                  C.byref(out)))
         return out.value
 
+    def extend_layer(self, layer_from_top, vecs):
+        """Hnsw::extend_layer  lib.rs:1039-1068"""
+        v = np.ascontiguousarray(vecs, dtype=np.uint64)
+        check(lib().phnsw_extend_layer(self._h, layer_from_top, _p(v), len(v)))
+
     def promote_at_layer(self, layer_from_top, bp=None):
         """lib.rs:1273-1427"""
         out = C.c_int()

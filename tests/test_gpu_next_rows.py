@@ -131,3 +131,28 @@ def test_store_append_keeps_ids_and_matches_a_whole_store():
     with pytest.raises(ph.PhnswError):
         grown.append(bad)
     assert grown.n == 800
+
+
+def test_extend_layer_matches_the_oracle():
+    """Hnsw::extend_layer lib.rs:1039-1068 through the ABI: same renumbering as the oracle's, search
+    over the extended stack still works, inserting an existing vector is refused (lib.rs:1797)"""
+    rows = oracle.synth_rows(0, 50, 8)
+    nodes = np.array([3, 10, 20, 30], dtype=np.uint64)
+    nb = np.array([[1, 2, EMPTY], [0, 3, EMPTY], [0, EMPTY, EMPTY], [1, EMPTY, EMPTY]], dtype=np.uint64)
+    oix = oracle.Index(rows, dim=8)
+    oix.push_layer(nodes, nb, 3)
+    assert oix.extend_layer(0, [15, 1]) == 0
+    store = ph.VectorStore(rows[:, :8])
+    g = ph.Hnsw.from_layers(store, [(nodes, nb)])
+    g.extend_layer(0, [15, 1])
+    on, onb = oix.layer(0)
+    np.testing.assert_array_equal(g._layer(0).nodes, on)
+    np.testing.assert_array_equal(g._layer(0).neighbors, onb)
+    gi, gd, gl = g.search_batch(qids=[3, 15], sp=ph.SearchParameters(4, 4, 2))
+    ci, cd, cl = oix.search(qids=[3, 15], sp=(4, 4, 2))
+    np.testing.assert_array_equal(gi, ci)
+    np.testing.assert_array_equal(gl, cl)
+    with pytest.raises(ph.PhnswError):
+        g.extend_layer(0, [10])
+    with pytest.raises(ph.PhnswError):
+        g.extend_layer(0, [40, 40])
