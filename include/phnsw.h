@@ -262,6 +262,9 @@ int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *d
 int phnsw_pq_set_table_mode(phnsw_store *s, int mode);
 int phnsw_pq_set_table_f16(phnsw_store *s, int on); /* = set_table_mode(s, on ? 1 : 0) */
 int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook);
+/* Quantizer::quantize / ::reconstruct  src/pq.rs:61-81 for n host vectors [n][dim] <-> codes [n][m] */
+int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64_t n, uint8_t *out_codes);
+int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, uint64_t n, float *out_rows);
 /* QuantizedHnsw::search  pq.rs:346-364 for a batch: search the index over the PQ store, re-rank
  * every result with the full-precision store, sort by (distance, id).  quantize_query != 0
  * quantises the query first like the reference (pq.rs:351-352); 0 = asymmetric (raw query

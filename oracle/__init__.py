@@ -264,6 +264,20 @@ def pq_create(rows, dim, m, ksub, seed=0, threads=8):
     return codes, codebook
 
 
+def pq_encode(rows, dim, codebook, threads=8):
+    """Quantizer::quantize for every row (orc_pq_encode): codes [n, m] u8"""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    cb = np.ascontiguousarray(codebook, dtype=np.float32)
+    m, ksub, dsub = cb.shape
+    assert m * dsub == dim
+    codes = np.zeros((rows.shape[0], m), dtype=np.uint8)
+    f = lib().orc_pq_encode
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    f(_p(rows), rows.shape[0], rows.shape[1], m, ksub, dsub, _p(cb), _p(codes), threads)
+    return codes
+
+
 def shuffle(ids, seed):
     v = np.array(ids, dtype=np.uint64)
     lib().orc_shuffle_u64(_p(v), len(v), seed)

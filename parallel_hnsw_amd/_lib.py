@@ -91,6 +91,8 @@ SYMBOLS = {
                                  C.POINTER(_u64)]),
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),
     "phnsw_pq_info": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "phnsw_pq_quantize": (_i32, [_vp, _vp, _u64, _vp]),
+    "phnsw_pq_reconstruct": (_i32, [_vp, _vp, _u64, _vp]),
     "phnsw_pq_set_table_mode": (_i32, [_vp, _i32]),
     "phnsw_pq_set_table_f16": (_i32, [_vp, _i32]),
     "phnsw_pq_read": (_i32, [_vp, _vp, _vp]),

@@ -208,6 +208,60 @@ extern "C" int phnsw_pq_set_table_mode(phnsw_store *s, int mode) {
 }
 extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) { return phnsw_pq_set_table_mode(s, on ? 1 : 0); }
 
+// Quantizer::quantize  pq.rs:61-71 for arbitrary vectors (exact nearest centroid per sub-space,
+// ties to the smaller centroid id) and Quantizer::reconstruct  pq.rs:73-81
+extern "C" int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64_t n, uint8_t *out_codes) {
+  if (!s || !s->codes || !rows || !out_codes) {
+    ph_set_error("phnsw_pq_quantize: needs a product-quantised store, rows and an output buffer");
+    return PHNSW_E_INVALID;
+  }
+  if (n == 0) return 0;
+  PH_HIP(hipSetDevice(s->device));
+  const uint32_t dim = s->dim;
+  float *rd = nullptr;
+  uint8_t *cd = nullptr;
+  hipError_t e = hipMalloc(&rd, (size_t)n * dim * 4);
+  if (e == hipSuccess) e = hipMalloc(&cd, (size_t)n * s->pq_m);
+  if (e == hipSuccess) e = hipMemcpy(rd, rows, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    uint32_t grid = (uint32_t)std::min<uint64_t>(n, 256u * 32u);
+    hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, rd, dim, n, s->pq_m, s->pq_ksub, s->pq_dsub,
+                       s->codebook, cd);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_codes, cd, (size_t)n * s->pq_m, hipMemcpyDeviceToHost);
+  if (rd) hipFree(rd);
+  if (cd) hipFree(cd);
+  if (e != hipSuccess) return ph_hip_fail(e, "pq quantize", __FILE__, __LINE__);
+  return 0;
+}
+
+extern "C" int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, uint64_t n, float *out_rows) {
+  if (!s || !s->codes || !codes || !out_rows) {
+    ph_set_error("phnsw_pq_reconstruct: needs a product-quantised store, codes and an output buffer");
+    return PHNSW_E_INVALID;
+  }
+  if (n == 0) return 0;
+  PH_HIP(hipSetDevice(s->device));
+  const uint32_t dim = s->dim;
+  float *rd = nullptr;
+  uint8_t *cd = nullptr;
+  hipError_t e = hipMalloc(&rd, (size_t)n * dim * 4);
+  if (e == hipSuccess) e = hipMalloc(&cd, (size_t)n * s->pq_m);
+  if (e == hipSuccess) e = hipMemcpy(cd, codes, (size_t)n * s->pq_m, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    uint64_t total = n * dim;
+    hipLaunchKernelGGL(ph_pq_reconstruct_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, cd, n, s->pq_m,
+                       s->pq_ksub, s->pq_dsub, s->codebook, rd, dim);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_rows, rd, (size_t)n * dim * 4, hipMemcpyDeviceToHost);
+  if (rd) hipFree(rd);
+  if (cd) hipFree(cd);
+  if (e != hipSuccess) return ph_hip_fail(e, "pq reconstruct", __FILE__, __LINE__);
+  return 0;
+}
+
 extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) {
   if (!s || !s->codes) {
     ph_set_error("not a product-quantised store");

@@ -174,6 +174,22 @@ class PqStore(VectorStore):
         check(lib().phnsw_pq_set_table_mode(self._h, mode))
         self.table_mode, self.table_f16 = mode, mode == 1
 
+    def quantize(self, rows):
+        """Quantizer::quantize  pq.rs:61-71 -> codes [n, m]"""
+        rows = np.ascontiguousarray(np.atleast_2d(rows), dtype=np.float32)
+        assert rows.shape[1] == self.dim
+        out = np.empty((rows.shape[0], self.m), dtype=np.uint8)
+        check(lib().phnsw_pq_quantize(self._h, _p(rows), rows.shape[0], _p(out)))
+        return out
+
+    def reconstruct(self, codes):
+        """Quantizer::reconstruct  pq.rs:73-81 -> rows [n, dim]"""
+        codes = np.ascontiguousarray(np.atleast_2d(codes), dtype=np.uint8)
+        assert codes.shape[1] == self.m
+        out = np.empty((codes.shape[0], self.dim), dtype=np.float32)
+        check(lib().phnsw_pq_reconstruct(self._h, _p(codes), codes.shape[0], _p(out)))
+        return out
+
     def codes(self):
         out = np.empty((self.n, self.m), dtype=np.uint8)
         check(lib().phnsw_pq_read(self._h, _p(out), None))

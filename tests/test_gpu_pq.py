@@ -181,3 +181,16 @@ def test_pq_rejects_bad_shapes():
             ph.PqStore(full, m, ksub)
     with pytest.raises(ph.PhnswError):
         ph.PqStore(ph.PqStore(full, 8, 16), 8, 16)  # a PQ store cannot be quantised again
+
+
+def test_quantize_and_reconstruct_arbitrary_vectors():
+    """Quantizer::quantize / reconstruct (pq.rs:61-81) for vectors that are not in the store"""
+    n, dim, m, ksub = 1200, 96, 24, 64
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=4)
+    fresh = oracle.synth_rows(2 ** 33, 500, dim)
+    codes = pq.quantize(fresh[:, :dim])
+    np.testing.assert_array_equal(codes, oracle.pq_encode(fresh, dim, ocb))
+    rec = pq.reconstruct(codes)
+    want = np.concatenate([ocb[j, codes[:, j]] for j in range(m)], axis=1)
+    np.testing.assert_array_equal(rec.view(np.uint32), want.view(np.uint32))
+    np.testing.assert_array_equal(pq.quantize(rows[:50, :dim]), ocodes[:50])  # stored rows: their own codes
