@@ -247,6 +247,25 @@ class QuantizedHnsw:
     def vector_count(self):
         return self.hnsw.vector_count()
 
+    # QuantizedHnsw forwards these to the Hnsw over the codes  pq.rs:366-411
+    def improve_index(self, bp=None, progress=None):
+        return self.hnsw.improve_index(bp or self.build_parameters_for_improve_index(), progress)
+
+    def improve_neighbors_upto(self, upto, bp=None, last_recall=None):
+        return self.hnsw.improve_neighbors_upto(upto, bp or self.build_parameters_for_improve_index(), last_recall)
+
+    def promote_at_layer(self, layer_from_top, bp=None):
+        return self.hnsw.promote_at_layer(layer_from_top, bp or self.hnsw.build_parameters)
+
+    def threshold_nn(self, threshold, probe_depth, initial_search_depth, max_out=64):
+        return self.hnsw.threshold_nn(threshold, probe_depth, initial_search_depth, max_out)
+
+    def stochastic_recall(self, op=None):
+        return self.hnsw.stochastic_recall(op)
+
+    def build_parameters_for_improve_index(self):
+        return self.hnsw.build_parameters
+
 
 class Layer:
     """Layer { neighborhood_size, nodes, neighbors }  lib.rs:85-91 (host copies, u64)"""
