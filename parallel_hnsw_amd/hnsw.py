@@ -388,6 +388,40 @@ class Hnsw:
         """counts from the bottom (lib.rs:604-606)"""
         return self._layer(self.layer_count() - i - 1)
 
+    def get_layer_from_top(self, i):
+        """lib.rs:617-624 (None past the stack)"""
+        return self._layer(i) if 0 <= i < self.layer_count() else None
+
+    def get_layer_above(self, i):
+        """lib.rs:631-637: the layer above layer-from-top i"""
+        return None if i == 0 else self.get_layer_from_top(i - 1)
+
+    def neighborhood_size(self):
+        return int(self.build_parameters.neighborhood_size)  # lib.rs:596-598
+
+    def zero_neighborhood_size(self):
+        return int(self.build_parameters.zero_layer_neighborhood_size)  # lib.rs:600-602
+
+    def comparator(self):
+        return self.store  # lib.rs:648-650
+
+    def __len__(self):
+        return self.vector_count()  # lib.rs:895-897
+
+    def is_empty(self):
+        return self.vector_count() == 0  # lib.rs:899-901
+
+    def all_vectors(self):
+        """lib.rs:968-975: the bottom layer's VectorIds"""
+        return self._layer(self.layer_count() - 1).nodes
+
+    def supers_for_layer(self, layer_id):
+        """lib.rs:977-984: the VectorIds of the layer above `layer_id` (counted from the bottom); the top
+        layer's only super is its entry node"""
+        if self.layer_count() == layer_id + 1:
+            return self.get_layer(layer_id).nodes[0:1]
+        return self.get_layer(layer_id + 1).nodes
+
     def entry_vector(self):
         return int(self._layer(0).nodes[0])
 
