@@ -266,3 +266,18 @@ def test_concurrent_host_threads_share_an_index():
         for r in range(3):
             for a, b in zip(got[t][r], want[t]):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_hnsw_accessors_mirror_the_crate():
+    """lib.rs:592-650, 895-901, 968-984"""
+    rows, ix = build_oracle_index(800, 16, seed=2, bp_kw=dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12))
+    store, g = to_gpu(rows, 16, ix, oracle.METRIC_COSINE_HALF)
+    L = g.layer_count()
+    assert len(g) == g.vector_count() == 800 and not g.is_empty()
+    assert g.comparator() is store
+    assert g.get_layer(0).node_count() == 800 and g.get_layer_from_top(L - 1).node_count() == 800
+    assert g.get_layer_from_top(L) is None and g.get_layer_above(0) is None
+    assert g.get_layer_above(L - 1).node_count() == g.get_layer(1).node_count()
+    assert list(g.all_vectors()) == list(range(800))
+    np.testing.assert_array_equal(g.supers_for_layer(0), g.get_layer(1).nodes)
+    assert list(g.supers_for_layer(L - 1)) == [g.entry_vector()]
