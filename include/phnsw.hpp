@@ -219,6 +219,15 @@ class Hnsw {
     check(phnsw_promote_at_layer(ix_, layer_from_top, &bp, &p));
     return p != 0;
   }
+  void extend_layer(uint32_t layer_from_top, const std::vector<VectorId> &vecs) {  // lib.rs:1039-1068
+    check(phnsw_extend_layer(ix_, layer_from_top, vecs.data(), vecs.size()));
+  }
+  // distance evaluations / hops of every search launched on this index (SearchStats summed)
+  std::pair<uint64_t, uint64_t> counters() const {
+    uint64_t a = 0, b = 0;
+    check(phnsw_index_counters(ix_, &a, &b));
+    return {a, b};
+  }
   // Hnsw::knn(k, probe_depth)  lib.rs:905-928
   std::vector<std::pair<VectorId, SearchResult>> knn(uint64_t k, uint64_t probe_depth) const {
     Layer bottom = get_layer(0);
