@@ -155,6 +155,7 @@ def main():
             dist.barrier()
         build_s = time.time() - t0
         b_dist, b_hops = index.counters()  # every search of the build rounds (this rank's share when sharded)
+        self_recall = index.stochastic_recall()  # the reference's own estimator (lib.rs:1463-1499): 10 % sample, self in the results
         build_bytes = b_dist * store.ld * 4 + b_hops * 48 * 4
         log("index built in %.1f s (%.0f vectors/s), layers %s" % (
             build_s, args.n / build_s, [index._layer(l).node_count() for l in range(index.layer_count())]))
@@ -275,6 +276,7 @@ def main():
             "elapsed": elapsed, "kernel_ms": k_ms, "alg_bytes": alg_bytes, "n_dist_per_query": n_dist / args.nq,
             "n_hops_per_query": n_hops / args.nq, "build_s": build_s, "build_mode": build_mode, "sweep": sweep,
             "batch_sweep": batch_sweep,
+            "build_self_recall": round(self_recall, 5),
             "build_roofline": {"bound": "hbm", "distance_evals": b_dist, "hops": b_hops,
                                "algorithmic_bytes": build_bytes, "achieved": round(build_bytes / build_s / 1e9, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(build_bytes / build_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -473,6 +475,7 @@ def main():
             "pq": pq,
             "batch_sweep": res["batch_sweep"],
             "build_roofline": res["build_roofline"],
+            "build_self_recall": res["build_self_recall"],
             "sweep": res["sweep"],
         }
         print(json.dumps(line), flush=True)
