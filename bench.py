@@ -142,7 +142,8 @@ def main():
                 eng = ph.GpuEngine(store, bp, device=dev)
                 comm = ph.TorchComm()
                 index = ph.ShardedBuilder(eng, comm).generate(np.arange(args.n, dtype=np.uint64))
-                build_mode = "sharded x%d, %.0f MB all-gathered per rank" % (world, comm.bytes_gathered / 1e6)
+                build_mode = "sharded x%d, %.0f MB all-gathered per rank in %.0f ms" % (
+                    world, comm.bytes_gathered / 1e6, comm.seconds * 1e3)
             except Exception as exc:  # keep the search measurement alive; say what happened
                 log("sharded build failed (%r); every rank builds the full index instead" % (exc,))
                 index = None

@@ -36,11 +36,14 @@ class TorchComm:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_gathered = 0
+        self.seconds = 0.0  # wall time inside the collectives (with their synchronisation)
 
     def all_gather(self, t):
         if self.world == 1:
             return t
+        import time
         import torch
+        t0 = time.perf_counter()
         staged = t.is_cuda and self.dist.get_backend(self.group) == "gloo"  # 1-GPU rehearsal only
         src = t.cpu() if staged else t.contiguous()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
@@ -48,7 +51,9 @@ class TorchComm:
         self.bytes_gathered += out.numel() * out.element_size()
         if t.is_cuda and not staged:
             torch.cuda.synchronize(t.device)  # libphnsw reads the result outside torch's stream bookkeeping
-        return out.to(t.device) if staged else out
+        out = out.to(t.device) if staged else out
+        self.seconds += time.perf_counter() - t0
+        return out
 
     def all_reduce_sum(self, values, device):
         if self.world == 1:
