@@ -155,6 +155,7 @@ struct PhSeedArgs {
   uint64_t layer_count;  // self.layer_count() in the seed expression  lib.rs:729-731
   uint64_t seed;
   uint32_t first, count;  // node range handled by this launch
+  const uint32_t *order;  // nullable: processing order within the range (locality schedule)
   uint32_t *rows;  // [count][W], row of node i at (i - first)
   float *rows_d;
 };
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(64) void ph_seed_rows_kernel(PhSeedArgs a) {
   extern __shared__ float dist_lds[];  // DistPQ table
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
-  for (uint32_t i = a.first + blockIdx.x; i < a.first + a.count; i += gridDim.x) {
+  for (uint32_t j = blockIdx.x; j < a.count; j += gridDim.x) {
+    const uint32_t i = a.first + (a.order ? a.order[j] : j);  // cell order: neighbouring nodes pick from the same partitions
     const uint32_t self_vec = a.nodes[i];
     Dist dist;
     dist.prepare_stored(a.dist, self_vec, dist_lds, lane);
@@ -860,6 +862,8 @@ static int layer_seed_impl(phnsw_index *ix, const phnsw_build_params *bp, const 
   a.seed = bp->seed;
   a.first = first;
   a.count = count;
+  a.order = nullptr;
+  PH_TRY(ph_layer_range_order(P->L, first, count, &a.order));
   a.rows = out_rows;
   a.rows_d = out_rows_d;
   dim3 g(s->codes ? pq_grid(s, count) : wave_grid(count));
