@@ -187,6 +187,24 @@ class ShardedBuilder:
             return t[:n]
         return self.comm.all_gather(t)[:n]
 
+    def _gather_many(self, ts, n):
+        """one collective for several per-node arrays of 4-byte elements (ids, distances, lengths):
+        packed side by side as int32 columns, gathered, split again"""
+        if n < self.SHARD_MIN:
+            return [t[:n] for t in ts]
+        import torch
+        if not all(isinstance(t, torch.Tensor) and t.element_size() == 4 for t in ts):
+            return [self._gather(t, n) for t in ts]
+        cols = [t.view(torch.int32).reshape(t.shape[0], -1) for t in ts]
+        full = self.comm.all_gather(torch.cat(cols, dim=1))[:n]
+        out, at = [], 0
+        for t, c in zip(ts, cols):
+            w = c.shape[1]
+            piece = full[:, at:at + w].contiguous().view(t.dtype)
+            out.append(piece.reshape((n,) + tuple(t.shape[1:])))
+            at += w
+        return out
+
     # generate_layer  lib.rs:675-823
     def generate_layer(self, vids, W):
         needs, K = self.e.layer_begin(vids, W)
@@ -196,10 +214,11 @@ class ShardedBuilder:
         chunk, first, count = self._range(n)
         ids, d, ln = self.e.empty((chunk, K), "id"), self.e.empty((chunk, K), "f32"), self.e.empty((chunk,), "id")
         self.e.layer_init_search(first, count, ids, d, ln)
-        ids_f, d_f, ln_f = self._gather(ids, n), self._gather(d, n), self._gather(ln, n)
+        ids_f, d_f, ln_f = self._gather_many([ids, d, ln], n)
         rows, rows_d = self.e.empty((chunk, W), "id"), self.e.empty((chunk, W), "f32")
         self.e.layer_seed(ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous(), first, count, rows, rows_d)
-        self.e.layer_finish(self._gather(rows, n).contiguous(), self._gather(rows_d, n).contiguous())
+        rows_f, rows_d_f = self._gather_many([rows, rows_d], n)
+        self.e.layer_finish(rows_f.contiguous(), rows_d_f.contiguous())
 
     # link_layer_to_better_neighbors  lib.rs:1070-1154
     def link_layer(self, lft, sp, M):
@@ -207,8 +226,8 @@ class ShardedBuilder:
         chunk, first, count = self._range(n)
         ids, d, ln = self.e.empty((chunk, M), "id"), self.e.empty((chunk, M), "f32"), self.e.empty((chunk,), "id")
         self.e.link_search(lft, sp, M, first, count, ids, d, ln)
-        return self.e.link_apply(lft, M, self._gather(ids, n).contiguous(), self._gather(d, n).contiguous(),
-                                 self._gather(ln, n).contiguous())
+        ids_f, d_f, ln_f = self._gather_many([ids, d, ln], n)
+        return self.e.link_apply(lft, M, ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous())
 
     # stochastic_recall_at  lib.rs:1463-1499
     def stochastic_recall_at(self, at):

@@ -185,3 +185,33 @@ def test_range_split_covers_everything():
                 assert first == min(n, r * chunk)
                 seen += list(range(first, first + count))
             assert seen == list(range(n))
+
+
+def test_packed_gather_splits_back_exactly():
+    """_gather_many: int32 ids, float32 distances and int32 lengths travel as one int32 block"""
+    import torch
+    from parallel_hnsw_amd.sharded import ShardedBuilder
+
+    class TwoRankComm:  # what rank 1 contributes = rank 0's block with every word's bits flipped
+        rank, world = 0, 2
+
+        def all_gather(self, t):
+            assert t.dtype == torch.int32 and t.dim() == 2
+            return torch.cat([t, ~t], 0)
+
+    class FakeEngine:
+        bp = None
+
+    b = ShardedBuilder(FakeEngine(), TwoRankComm(), shard_min=0)
+    chunk, M = 5, 3
+    ids = torch.arange(chunk * M, dtype=torch.int32).reshape(chunk, M)
+    d = torch.linspace(-1, 1, chunk * M, dtype=torch.float32).reshape(chunk, M)
+    ln = torch.arange(chunk, dtype=torch.int32) + 7
+    n = 8  # the second rank's last two rows fall off
+    gi, gd, gl = b._gather_many([ids, d, ln], n)
+    assert gi.shape == (n, M) and gd.shape == (n, M) and gl.shape == (n,)
+    assert gi.dtype == torch.int32 and gd.dtype == torch.float32 and gl.dtype == torch.int32
+    assert torch.equal(gi[:chunk], ids) and torch.equal(gd[:chunk], d) and torch.equal(gl[:chunk], ln)
+    assert torch.equal(gi[chunk:], (~ids)[: n - chunk])
+    assert torch.equal(gd[chunk:].view(torch.int32), (~d.view(torch.int32))[: n - chunk])
+    assert torch.equal(gl[chunk:], (~ln)[: n - chunk])
