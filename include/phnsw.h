@@ -140,9 +140,12 @@ int phnsw_generate_layer(phnsw_index *ix, const uint64_t *vids, uint64_t n,
 /* link_layer_to_better_neighbors  src/lib.rs:1070-1154 ; *out_added = new edges */
 int phnsw_link_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
                      uint64_t link_count, uint64_t *out_added);
-/* Hnsw::improve_index  src/lib.rs:1664-1686 (promotion not performed) */
-int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb,
-                        void *user, float *out_recall);
+/* Hnsw::improve_index(bp, last_recall, progress)  src/lib.rs:1664-1686, promotion included
+ * (bp->promote).  last_recall: NaN = None (the recall is estimated first, lib.rs:1671); a number is
+ * taken as the current recall, exactly like Some(r) -- it only saves that first estimate, every
+ * improve_index_at call below is made with None (lib.rs:1679). */
+int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, float last_recall,
+                        phnsw_progress_cb cb, void *user, float *out_recall);
 /* Hnsw::improve_neighbors_upto  src/lib.rs:1515-1544 ; last_recall NaN = None */
 int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
                                  float last_recall, float *out_recall);
@@ -198,6 +201,13 @@ int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, u
  * summed): the build's algorithmic bytes are n_dist * row bytes + n_hops * neighbour-row bytes */
 int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uint64_t *n_hops);
 int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
+/* the same descent dispatch by dispatch (measurement only): entry 0 = the dense-top-layer tile pass
+ * (csrc/tiny.hip; layers 0..0), then one entry per launch of the search kernel: layers
+ * [layer_lo, layer_hi), milliseconds, distance evaluations and hops.  *count = entries available;
+ * at most cap are written; any output array may be NULL. */
+int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap, uint32_t *count, float *ms,
+                                 uint64_t *n_dist, uint64_t *n_hops, uint32_t *layer_lo,
+                                 uint32_t *layer_hi);
 
 /* ---- phase API: the per-round pieces of phnsw_generate_layer / phnsw_link_layer /
  * phnsw_stochastic_recall_at over a NODE RANGE, device buffers, u32 ids (0xFFFFFFFF empty).

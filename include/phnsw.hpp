@@ -199,9 +199,10 @@ class Hnsw {
       for (uint64_t j = 0; j < len[i]; j++) out[i].push_back({ids[i * ef + j], d[i * ef + j]});
     return out;
   }
-  float improve_index(const BuildParameters &bp) {  // lib.rs:1664-1686
+  // improve_index(bp, last_recall: Option<f32>, progress)  lib.rs:1664-1686; NaN = None
+  float improve_index(const BuildParameters &bp, float last_recall = __builtin_nanf("")) {
     float r = 0;
-    check(phnsw_improve_index(ix_, &bp, nullptr, nullptr, &r));
+    check(phnsw_improve_index(ix_, &bp, last_recall, nullptr, nullptr, &r));
     return r;
   }
   float improve_neighbors(const BuildParameters &bp) {  // lib.rs:1507-1513

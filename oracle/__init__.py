@@ -135,6 +135,8 @@ def lib():
         L.orc_improve_neighbors_upto.argtypes = [vp, u32, C.POINTER(BuildParams), f32, i32]
         L.orc_improve_index.restype = f32
         L.orc_improve_index.argtypes = [vp, C.POINTER(BuildParams), i32]
+        L.orc_improve_index_from.restype = f32
+        L.orc_improve_index_from.argtypes = [vp, C.POINTER(BuildParams), f32, i32]
         L.orc_promote_at_layer.restype = i32
         L.orc_promote_at_layer.argtypes = [vp, u32, C.POINTER(BuildParams), i32]
         L.orc_discover_hits.restype = i32
@@ -152,6 +154,8 @@ def lib():
         L.orc_shuffle_u64.argtypes = [vp, u64, u64]
         L.orc_synth_rows.argtypes = [vp, u64, u64, u32, u32, u64, i32, i32]
         L.orc_synth_clustered_rows.argtypes = [vp, u64, u64, u32, u32, u64, u32, f32, i32]
+        L.orc_first_touch.argtypes = [vp, u64, i32]
+        L.orc_first_touch.restype = None
         L.orc_pq_create.restype = i32
         L.orc_pq_create.argtypes = [vp, u64, u32, u32, u32, u32, u64, vp, vp, i32]
         L.orc_index_set_pq.argtypes = [vp, vp, vp, u32, u32, u32]
@@ -250,6 +254,45 @@ def synth_clustered_rows(first, count, dim, seed=42, n_clusters=1000, noise=1.0,
     rows = np.zeros((count, ld), dtype=np.float32)
     lib().orc_synth_clustered_rows(_p(rows), first, count, dim, ld, seed, n_clusters, noise, threads)
     return rows
+
+
+def empty_rows_first_touched(n, dim, threads=8):
+    """[n, dim] f32 whose pages were first written by `threads` OpenMP threads (static schedule)"""
+    rows = np.empty((n, dim), dtype=np.float32)
+    lib().orc_first_touch(_p(rows), rows.size, threads)
+    return rows
+
+
+def tie_swap_report(a_ids, a_d, b_ids, b_d, k=10, rel=1e-5):
+    """Two result lists of the same queries computed with different f32 summation orders (e.g. the GPU's
+    blocked sum and the reference's sequential sum, bigvec.rs:48-51) may only differ by near-tie swaps
+    (SURVEY 7.3): for every slot s < k whose ids differ, each of the two ids must also be in the OTHER
+    list (anywhere in its full length), at a position whose distance -- in that list's own arithmetic --
+    is within `rel` (relative) of that list's distance at slot s: the two ids sit in one tie group and
+    only their order changed.  Returns counts; `unexplained` must be 0."""
+    a_ids, b_ids = np.asarray(a_ids), np.asarray(b_ids)
+    a_d, b_d = np.asarray(a_d, dtype=np.float64), np.asarray(b_d, dtype=np.float64)
+    nq = a_ids.shape[0]
+    differing = explained = 0
+    worst = 0.0
+    for q in np.nonzero((a_ids[:, :k] != b_ids[:, :k]).any(1))[0]:
+        for s in np.nonzero(a_ids[q, :k] != b_ids[q, :k])[0]:
+            differing += 1
+            ok = True
+            for x, ids_o, d_o in ((a_ids[q, s], b_ids[q], b_d[q]), (b_ids[q, s], a_ids[q], a_d[q])):
+                pos = np.nonzero(ids_o == x)[0]
+                if not len(pos):
+                    ok = False
+                    break
+                gap = abs(d_o[pos[0]] - d_o[s]) / max(abs(d_o[s]), 1e-30)
+                worst = max(worst, gap) if gap <= rel else worst
+                if gap > rel:
+                    ok = False
+                    break
+            explained += int(ok)
+    return {"queries": int(nq), "k": int(k), "slots_equal": round(float((a_ids[:, :k] == b_ids[:, :k]).mean()), 6),
+            "differing_slots": int(differing), "explained_as_near_tie_swaps": int(explained),
+            "unexplained": int(differing - explained), "rel_tolerance": rel, "largest_tie_gap_rel": float(worst)}
 
 
 def pq_create(rows, dim, m, ksub, seed=0, threads=8):
@@ -423,8 +466,9 @@ class Index:
     def improve_neighbors_upto(self, upto, bp, last_recall=float("nan"), threads=8):
         return lib().orc_improve_neighbors_upto(self.h, upto, C.byref(bp), last_recall, threads)
 
-    def improve_index(self, bp, threads=8):
-        return lib().orc_improve_index(self.h, C.byref(bp), threads)
+    def improve_index(self, bp, threads=8, last_recall=None):
+        return lib().orc_improve_index_from(self.h, C.byref(bp), float("nan") if last_recall is None else last_recall,
+                                            threads)
 
     # -- product quantisation (pq.rs) --
     def set_pq(self, codes, codebook, table_f16=False):

@@ -192,6 +192,7 @@ float orc_improve_neighbors_upto(orc_index *ix, uint32_t upto, const orc_build_p
                                  float last_recall_or_nan, int threads);
 /* improve_index lib.rs:1664-1686 minus promotion */
 float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads);
+float orc_improve_index_from(orc_index *ix, const orc_build_params *bp, float last_recall, int threads);
 /* discover_unreachable_vectors lib.rs:1002-1037 ; returns count, *out malloc'd (caller frees) */
 uint64_t orc_discover_unreachable(const orc_index *ix, uint32_t layer_from_top, orc_search_params sp,
                                   uint64_t **out, int threads);
@@ -213,6 +214,7 @@ void orc_shuffle_u64(uint64_t *v, uint64_t n, uint64_t seed);
  * (seed+i, j), L2-normalised in f32 when normalize != 0 */
 void orc_synth_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                     uint64_t seed, int normalize, int threads);
+void orc_first_touch(float *p, uint64_t n_floats, int threads);
 void orc_synth_clustered_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                               uint64_t seed, uint32_t n_clusters, float noise, int threads);
 /* ---- product quantisation (pq.rs; per-sub-space codebooks, u8 codes: BASELINE config 5) ---- */

@@ -935,15 +935,19 @@ static float improve_index_at(orc_index *ix, uint32_t *lft_io, const orc_build_p
   return recall;
 }
 
-/* improve_index  src/lib.rs:1664-1686 */
-float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads) {
-  float recall = orc_stochastic_recall_at(ix, ix->layer_count - 1, &bp->optimization, threads);
+/* improve_index  src/lib.rs:1664-1686; last_recall NaN = None (unwrap_or_else :1671) */
+float orc_improve_index_from(orc_index *ix, const orc_build_params *bp, float last_recall, int threads) {
+  float recall = last_recall == last_recall ? last_recall
+                                            : orc_stochastic_recall_at(ix, ix->layer_count - 1, &bp->optimization, threads);
   uint32_t lft = 0;
   while (lft < ix->layer_count) {
     recall = improve_index_at(ix, &lft, bp, threads);
     lft++;
   }
   return recall;
+}
+float orc_improve_index(orc_index *ix, const orc_build_params *bp, int threads) {
+  return orc_improve_index_from(ix, bp, NAN, threads);
 }
 
 /* Hnsw::generate  src/lib.rs:825-893 */

@@ -143,6 +143,15 @@ void orc_synth_rows(float *rows, uint64_t first, uint64_t count, uint32_t dim, u
   }
 }
 
+/* pages of a freshly allocated buffer touched by the threads that will read them (static
+ * schedule, like the search loops): bench.py's cpu_baseline fills the buffer afterwards */
+void orc_first_touch(float *p, uint64_t n_floats, int threads) {
+  const uint64_t page = 1024; /* floats per 4 KiB page */
+  const uint64_t pages = (n_floats + page - 1) / page;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (uint64_t i = 0; i < pages; i++) p[i * page] = 0.0f;
+}
+
 /* Clustered synthetic rows (SURVEY section 8d's second dataset): n_clusters unit centres
  * (synthetic normalised rows keyed seed ^ CENTRE_SALT), point i belongs to cluster
  * mulhi(mix64(..i..), n_clusters) and is normalise(centre + a * u), u_j uniform(-1,1) keyed

@@ -61,7 +61,7 @@ SYMBOLS = {
     "phnsw_build": (_i32, [_vp, _vp, _u64, C.POINTER(BuildParams), _vp, _vp, _pp]),
     "phnsw_generate_layer": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams)]),
     "phnsw_link_layer": (_i32, [_vp, _u32, C.POINTER(SearchParams), _u64, C.POINTER(_u64)]),
-    "phnsw_improve_index": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, C.POINTER(_f32)]),
+    "phnsw_improve_index": (_i32, [_vp, C.POINTER(BuildParams), _f32, _vp, _vp, C.POINTER(_f32)]),
     "phnsw_improve_neighbors_upto": (_i32, [_vp, _u32, C.POINTER(BuildParams), _f32, C.POINTER(_f32)]),
     "phnsw_extend_layer": (_i32, [_vp, _u32, _vp, _u64]),
     "phnsw_promote_at_layer": (_i32, [_vp, _u32, C.POINTER(BuildParams), C.POINTER(_i32)]),
@@ -77,6 +77,7 @@ SYMBOLS = {
                                          _vp, _vp, _vp, _vp]),
     "phnsw_index_counters": (_i32, [_vp, _vp, _vp]),
     "phnsw_last_search_kernel_ms": (_i32, [_vp, C.POINTER(_f32)]),
+    "phnsw_last_search_dispatches": (_i32, [_vp, _u32, C.POINTER(_u32), _vp, _vp, _vp, _vp, _vp]),
     "phnsw_index_create": (_i32, [_vp, C.POINTER(BuildParams), _pp]),
     "phnsw_build_plan": (_i32, [_vp, _u64, C.POINTER(BuildParams), _vp, _vp, _u32, C.POINTER(_u32)]),
     "phnsw_layer_begin": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams), C.POINTER(_i32)]),

@@ -622,14 +622,17 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   int rc = ph_workspace_ensure(ix, ws, std::max(a.ef, a.cap_max), ovf_cap ? ovf_cap : default_ovf_cap(a.ef));
   if (rc) return rc;
   // Large batches of independent queries descend in several launches: the small top layers in
-  // the caller's order, then every large layer in a launch of its own with the queries sorted by
-  // where they landed in the layer above (cell of the best candidate), one contiguous eighth of
-  // that order per XCD.  Same arithmetic per query, so the results are identical; neighbouring
-  // queries now share rows in L2 / the Infinity Cache.  Between launches the running candidates
-  // are parked in the output rows.
+  // the caller's order, then every layer whose rows exceed one XCD's L2 in a launch of its own with
+  // the queries sorted by where they landed in the layer above (cell of the best candidate), one
+  // contiguous eighth of that order per XCD.  Same arithmetic per query, so the results are
+  // identical; neighbouring queries now share rows in L2 / the Infinity Cache.  Between launches
+  // the running candidates are parked in the output rows.
+  // (layers evaluated densely, tiny.hip, never read a vector row during the traversal: they stay in
+  // the first launch whatever their size)
+  const uint32_t T = knn_mode ? 0u : ph_tiny_layer_count(ix, a.n_layers, a.ef);
   uint32_t first_big = a.n_layers;
-  for (uint32_t l = 1; l < a.n_layers; l++)
-    if (ix->layers[l].n_nodes >= PH_SPLIT_MIN) {
+  for (uint32_t l = std::max(1u, T); l < a.n_layers; l++)
+    if (ph_layer_own_launch(ix->layers[l].n_nodes, ix->store->ld)) {
       first_big = l;
       break;
     }
@@ -645,25 +648,74 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   const bool split = ix->store->rows && !a.order && !knn_mode && !out_stride && first_big < a.n_layers &&
                      nq >= PH_TWO_LAUNCH_MIN &&
                      !getenv("PHNSW_NO_LOCALITY");
-  if (!split) return ph_search_launch(ix, ws, a, stream);
-  g_two_launch_count++;
-  rc = ph_workspace_order_ensure(ws, a.nq);
-  for (uint32_t l = first_big; l < a.n_layers && !rc; l++)
-    rc = ph_layer_anchor_pos(ix->store, mix->layers[l - 1]);  // first use on a loaded index; no-op afterwards
-  if (rc) return rc;
-  uint32_t *const out_hit_final = a.out_hit;
-  for (uint32_t lo = 0, hi = first_big; lo < a.n_layers; lo = hi, hi = hi + 1) {
-    PhSearchArgs p = a;
-    const bool last = hi == a.n_layers;
-    p.layer_lo = lo;
-    p.layer_hi = hi;
-    p.order = lo ? ws.oorder : nullptr;
-    p.out_hit = last ? out_hit_final : nullptr;
-    p.out_key = last ? nullptr : ws.okey;
-    p.key_pos = last ? nullptr : ix->layers[hi - 1].pos;
-    rc = ph_search_launch(ix, ws, p, stream, lo == 0, last);
-    if (!rc && !last) rc = ph_workspace_order_sort(ws, a.nq, stream);
+  if (split) {
+    g_two_launch_count++;
+    rc = ph_workspace_order_ensure(ws, a.nq);
+    for (uint32_t l = first_big; l < a.n_layers && !rc; l++)
+      rc = ph_layer_anchor_pos(ix->store, mix->layers[l - 1]);  // first use on a loaded index; no-op afterwards
     if (rc) return rc;
+  }
+  rc = ph_search_begin(ws, stream);
+  if (rc) return rc;
+  // The dense top layers (tiny.hip) keep one table row per launch position; a query list longer
+  // than the table may hold runs in consecutive chunks of the list (same workspace, same stream).
+  const uint64_t tmax = T ? ph_tiny_max_positions(ix, a.n_layers, a.ef) : 0;
+  const uint64_t chunk = (tmax && nq > tmax) ? tmax : nq;
+  for (uint64_t c0 = 0; c0 < nq; c0 += chunk) {
+    PhSearchArgs b = a;
+    const uint64_t cnt = std::min<uint64_t>(chunk, nq - c0);
+    const bool last_chunk = c0 + cnt == nq;
+    b.nq = (uint32_t)cnt;
+    if (b.order) {
+      b.order += c0;  // positions [c0, c0 + cnt) of the processing order; query indices stay global
+    } else if (c0) {
+      const uint32_t ostride = out_stride ? out_stride : b.ef;
+      if (b.queries) b.queries += c0 * ldq;
+      if (b.qids) b.qids += c0;
+      if (b.exclude) b.exclude += c0;
+      b.out_ids += c0 * ostride;
+      b.out_d += c0 * ostride;
+      b.out_len += c0;
+      if (b.out_stats) b.out_stats += 2 * c0;
+      b.status += c0;
+      if (b.out_hit) b.out_hit += c0;
+      b.first_node += (uint32_t)c0;
+    }
+    rc = ph_tiny_prepare(ix, ws, b, T, stream);
+    if (rc) return rc;
+    ws.d_tiny = b.tiny_layers != 0;
+    PH_HIP(hipEventRecord(ws.evd[0], stream));
+    if (!split) {
+      b.launch_totals = ws.dtotals;
+      rc = ph_search_launch(ix, ws, b, stream, last_chunk);
+      if (rc) return rc;
+      PH_HIP(hipEventRecord(ws.evd[1], stream));
+      ws.n_dispatch = 1;
+      ws.d_lo[0] = knn_mode ? b.n_layers - 1 : 0;
+      ws.d_hi[0] = b.n_layers;
+      continue;
+    }
+    uint32_t di = 0;
+    uint32_t *const out_hit_final = b.out_hit;
+    for (uint32_t lo = 0, hi = first_big; lo < b.n_layers; lo = hi, hi = hi + 1) {
+      PhSearchArgs p = b;
+      const bool last = hi == b.n_layers;
+      p.layer_lo = lo;
+      p.layer_hi = hi;
+      if (lo) p.tiny_layers = 0;
+      p.order = lo ? ws.oorder : nullptr;
+      p.out_hit = last ? out_hit_final : nullptr;
+      p.out_key = last ? nullptr : ws.okey;
+      p.key_pos = last ? nullptr : ix->layers[hi - 1].pos;
+      p.launch_totals = ws.dtotals + 2 * di;
+      rc = ph_search_launch(ix, ws, p, stream, last && last_chunk);
+      if (!rc && !last) rc = ph_workspace_order_sort(ws, b.nq, stream);
+      if (rc) return rc;
+      PH_HIP(hipEventRecord(ws.evd[1 + di], stream));
+      ws.d_lo[di] = lo;
+      ws.d_hi[di] = hi;
+      ws.n_dispatch = ++di;
+    }
   }
   return 0;
 }
@@ -724,6 +776,39 @@ extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
   }
   PH_HIP(hipEventSynchronize(ws.ev1));
   PH_HIP(hipEventElapsedTime(ms, ws.ev0, ws.ev1));
+  return 0;
+}
+
+// the last descent on this index, dispatch by dispatch: entry 0 = the dense-top-layer kernels
+// (layer_lo = layer_hi = 0, no counters; 0 ms when the descent had none), then one entry per launch
+// of the search kernel with the layers it covered, its time (HIP events on its stream; a launch's
+// time includes the key sort in front of it) and the distance evaluations / hops it performed
+extern "C" int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap, uint32_t *count, float *ms,
+                                            uint64_t *n_dist, uint64_t *n_hops, uint32_t *layer_lo,
+                                            uint32_t *layer_hi) {
+  if (!ix || !count) return PHNSW_E_INVALID;
+  phnsw_index *mix = const_cast<phnsw_index *>(ix);
+  std::lock_guard<std::mutex> g(mix->ws_mutex);
+  PhWorkspace &ws = mix->ws[mix->ws_last];
+  if (!ws.timed) {
+    ph_set_error("no search has been launched on this index");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(ix->store->device));
+  PH_HIP(hipEventSynchronize(ws.ev1));
+  unsigned long long h[2 * PH_MAX_DISPATCH];
+  PH_HIP(hipMemcpy(h, ws.dtotals, sizeof(h), hipMemcpyDeviceToHost));
+  const uint32_t n = ws.n_dispatch + 1;
+  *count = n;
+  for (uint32_t i = 0; i < n && i < cap; i++) {
+    float t = 0.f;
+    PH_HIP(hipEventElapsedTime(&t, i == 0 ? ws.ev0 : ws.evd[i - 1], ws.evd[i]));
+    if (ms) ms[i] = t;
+    if (n_dist) n_dist[i] = i ? h[2 * (i - 1)] : 0;
+    if (n_hops) n_hops[i] = i ? h[2 * (i - 1) + 1] : 0;
+    if (layer_lo) layer_lo[i] = i ? ws.d_lo[i - 1] : 0;
+    if (layer_hi) layer_hi[i] = i ? ws.d_hi[i - 1] : 0;
+  }
   return 0;
 }
 

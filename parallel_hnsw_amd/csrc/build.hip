@@ -1463,14 +1463,15 @@ static int improve_index_at_impl(phnsw_index *ix, uint32_t *lft_io, const phnsw_
   return 0;
 }
 
-static int improve_index_impl(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb, void *user,
-                              float *out) {
+static int improve_index_impl(phnsw_index *ix, const phnsw_build_params *bp, float last_recall, phnsw_progress_cb cb,
+                              void *user, float *out) {
   if (ix->layers.empty()) {
     ph_set_error("improve_index: index has no layers");
     return PHNSW_E_INVALID;
   }
-  float recall = 0.f;
-  PH_TRY(recall_impl(ix, (uint32_t)ix->layers.size() - 1, &bp->optimization, &recall));
+  // last_recall.unwrap_or_else(|| self.stochastic_recall(bp.optimization))  lib.rs:1671
+  float recall = last_recall;
+  if (last_recall != last_recall) PH_TRY(recall_impl(ix, (uint32_t)ix->layers.size() - 1, &bp->optimization, &recall));
   uint32_t lft = 0;
   while (lft < ix->layers.size()) {  // lib.rs:1673-1683
     PH_TRY(improve_index_at_impl(ix, &lft, bp, &recall));
@@ -1522,11 +1523,11 @@ extern "C" int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, cons
   return improve_neighbors_upto_impl(ix, upto, bp, last_recall, out_recall);
 }
 
-extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, phnsw_progress_cb cb, void *user,
-                                   float *out_recall) {
+extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, float last_recall,
+                                   phnsw_progress_cb cb, void *user, float *out_recall) {
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
-  return improve_index_impl(ix, bp, cb, user, out_recall);
+  return improve_index_impl(ix, bp, last_recall, cb, user, out_recall);
 }
 
 // ---- phase entry points for multi-GPU drivers (device buffers, u32 ids) ----
@@ -1623,7 +1624,7 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
     uint64_t W = level == 0 ? bp->zero_layer_neighborhood_size : bp->neighborhood_size;
     int rc = generate_layer_impl(ix, vs.data(), length, W, bp);
     size_t old_count = ix->layers.size();
-    if (!rc) rc = improve_index_impl(ix, bp, nullptr, nullptr, nullptr);  // lib.rs:877
+    if (!rc) rc = improve_index_impl(ix, bp, NAN, nullptr, nullptr, nullptr);  // improve_index(bp, None, progress)  lib.rs:877
     if (!rc && cb && cb(user, "generate", i + 1, parts.size())) {
       ph_set_error("interrupted by the progress callback");
       rc = PHNSW_E_INVALID;

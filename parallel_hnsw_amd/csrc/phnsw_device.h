@@ -49,6 +49,33 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ORC_SUM_BLOCKED64 restates).  All U*NV loads are issued before the first use so that U
 // rows are in flight per wave; out-of-range chunks (dim not a multiple of 256) load a
 // clamped address and are skipped in the accumulate by a select, not a branch.
+// the fma chain itself: chunks lane, lane+64, ... of one row (already in registers) against the
+// query's chunks.  Every kernel that evaluates a distance goes through this function, so the
+// bits of a distance do not depend on which kernel produced it (search, dense top-layer table,
+// seeding, row distances).
+template <int NV, bool EXACT, bool L2>
+__device__ __forceinline__ float chain_partial(const float4 (&x)[NV], const float4 (&q)[NV], uint32_t nv4, uint32_t lane) {
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    float t = a;
+    if (L2) {
+      float d0 = q[k].x - x[k].x, d1 = q[k].y - x[k].y, d2 = q[k].z - x[k].z, d3 = q[k].w - x[k].w;
+      t = fmaf(d0, d0, t);
+      t = fmaf(d1, d1, t);
+      t = fmaf(d2, d2, t);
+      t = fmaf(d3, d3, t);
+    } else {
+      t = fmaf(q[k].x, x[k].x, t);
+      t = fmaf(q[k].y, x[k].y, t);
+      t = fmaf(q[k].z, x[k].z, t);
+      t = fmaf(q[k].w, x[k].w, t);
+    }
+    a = (EXACT || lane + 64u * k < nv4) ? t : a;
+  }
+  return a;
+}
+
 template <int NV, int U, bool EXACT, bool L2>
 __device__ __forceinline__ void rows_partial_impl(const float4 *const (&row)[U], const float4 (&q)[NV], uint32_t nv4,
                                                   uint32_t lane, float (&acc)[U]) {
@@ -63,27 +90,7 @@ __device__ __forceinline__ void rows_partial_impl(const float4 *const (&row)[U],
     }
   }
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      float t = a;
-      if (L2) {
-        float d0 = q[k].x - x[u][k].x, d1 = q[k].y - x[u][k].y, d2 = q[k].z - x[u][k].z, d3 = q[k].w - x[u][k].w;
-        t = fmaf(d0, d0, t);
-        t = fmaf(d1, d1, t);
-        t = fmaf(d2, d2, t);
-        t = fmaf(d3, d3, t);
-      } else {
-        t = fmaf(q[k].x, x[u][k].x, t);
-        t = fmaf(q[k].y, x[u][k].y, t);
-        t = fmaf(q[k].z, x[u][k].z, t);
-        t = fmaf(q[k].w, x[u][k].w, t);
-      }
-      a = (EXACT || lane + 64u * k < nv4) ? t : a;
-    }
-    acc[u] = a;
-  }
+  for (int u = 0; u < U; u++) acc[u] = chain_partial<NV, EXACT, L2>(x[u], q, nv4, lane);
 }
 
 template <int NV, int U>

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -13,6 +14,10 @@
 #define PH_FMAX 3.4028234663852886e38f
 #define PH_MAX_LAYERS 24
 #define PH_WAVE 64
+#define PH_MAX_DISPATCH 24  // search launches of one descent (<= PH_MAX_LAYERS)
+#define PH_TINY_MAX_NODES 8192u      // largest layer evaluated densely (tiny.hip)
+#define PH_TINY_LDS_NODES 1024u      // up to here a query's table row is staged in LDS
+#define PH_TINY_MAX_LAYERS 8
 
 void ph_set_error(const char *fmt, ...);
 int ph_hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -98,6 +103,21 @@ struct PhWorkspace {
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t order_cap = 0;
+  // dense top layers (tiny.hip): distance table [positions][stride], neighbour rows in table ids,
+  // per-node layer membership (+ one flag word)
+  float *tiny_d = nullptr;
+  size_t tiny_d_bytes = 0;
+  uint32_t *tiny_nbr = nullptr;
+  size_t tiny_nbr_bytes = 0;
+  uint32_t *tiny_member = nullptr;
+  size_t tiny_member_bytes = 0;
+  // per-dispatch bookkeeping of the last descent (phnsw_last_search_dispatches): evd[0] closes the
+  // dense-top-layer kernels, evd[1 + i] search launch i; dtotals[i] = {distance evaluations, hops}
+  hipEvent_t evd[PH_MAX_DISPATCH + 1] = {};
+  unsigned long long *dtotals = nullptr;  // device [PH_MAX_DISPATCH][2]
+  uint32_t n_dispatch = 0;
+  uint32_t d_lo[PH_MAX_DISPATCH] = {}, d_hi[PH_MAX_DISPATCH] = {};
+  bool d_tiny = false;
 };
 
 struct PhPendingLayer;
@@ -147,6 +167,7 @@ struct PhSearchArgs {
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
   unsigned long long *totals;   // nullable: [2] running sums of distance evaluations / hops (all launches)
+  unsigned long long *launch_totals;  // nullable: [2] the same for this launch alone
   void *pq_tables;              // PQ store: per-wave lookup-table slots in global memory (DistPQG)
   uint32_t pq_table_bytes;      // bytes per slot
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip
@@ -155,6 +176,15 @@ struct PhSearchArgs {
   const uint32_t *order;  // nullable: processing order (a permutation of 0..nq-1), see search.hip
   uint32_t seg;           // order != nullptr: positions per XCD segment
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
+  // dense top layers (tiny.hip): layers [0, tiny_layers) of this launch hold <= PH_TINY_MAX_NODES
+  // nodes; the distance of every query to every node of layer tiny_layers - 1 sits in tiny_d
+  // (same bits as the per-hop evaluation), the traversal of those layers runs in the id space
+  // of that layer ("table ids") with its visited set in LDS (and its table row, when small)
+  uint32_t tiny_layers, tiny_n, tiny_stride;
+  const float *tiny_d;          // [launch positions][tiny_stride]
+  const uint32_t *tiny_nbr;     // layer l: [tiny_n][W_l] at tiny_off[l], table ids, PH_EMPTY32 padded
+  const uint32_t *tiny_member;  // [tiny_n] bit l = node of layer l; [tiny_n] != 0: layers not nested, table off
+  uint32_t tiny_off[PH_TINY_MAX_LAYERS];
 };
 
 uint32_t ph_default_ovf_cap(uint32_t ef);
@@ -177,15 +207,33 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
 // locality schedule helpers (group.hip / api.hip)
 #define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
 #define PH_POS_MIN 256u     // smaller layers carry no cells (their node id is the key)
-#define PH_SPLIT_MIN 32768u // a layer at least this large gets a launch of its own in a split descent
+// a layer whose vector rows do not fit one XCD's L2 (4 MiB) gets a launch of its own in a split
+// descent, its queries sorted by the cell they arrive in (PHNSW_SPLIT_BYTES overrides: tuning knob)
+#define PH_SPLIT_BYTES (4ull << 20)
+static inline bool ph_layer_own_launch(uint64_t n_nodes, uint32_t ld) {
+  static const uint64_t limit = [] {
+    const char *e = getenv("PHNSW_SPLIT_BYTES");
+    return (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (uint64_t)PH_SPLIT_BYTES;
+  }();
+  return n_nodes * (uint64_t)ld * 4u > limit;
+}
 int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip
 void ph_store_anchors_free(phnsw_store *s);
 int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st);
 int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const uint32_t **out);
 
+// dense top layers (tiny.hip): decides how many leading layers of the launch described by `a` run
+// against a distance table, fills a.tiny_* and enqueues the table kernels for launch positions
+// [0, npos) (position p = query order[p], or p itself) on `stream`.  a.tiny_layers = 0 when unused.
+int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uint32_t max_layers, hipStream_t stream);
+size_t ph_tiny_lds_bytes(const PhSearchArgs &a);
+uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t ef);  // leading layers a launch may run densely
+uint64_t ph_tiny_max_positions(const phnsw_index *ix, uint32_t n_layers, uint32_t ef);  // 0 = no dense layers for this launch shape
+void ph_tiny_free(PhWorkspace &ws);
+
 // launchers (search.hip)
-int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream,
-                     bool mark_begin = true, bool mark_end = true);
+int ph_search_begin(PhWorkspace &ws, hipStream_t stream);
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end = true);
 int ph_workspace_order_ensure(PhWorkspace &ws, uint32_t nq);                          // group.hip
 int ph_workspace_order_sort(PhWorkspace &ws, uint32_t nq, hipStream_t stream);        // group.hip
 void ph_workspace_order_free(PhWorkspace &ws);                                        // group.hip

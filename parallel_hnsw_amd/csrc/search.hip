@@ -48,6 +48,13 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   uint32_t *S = smem + 4 * CAP;            // prefix scratch [CAP + 64]
   float *dist_lds = (float *)(smem + 5 * CAP + 64);  // DistPQ: the query's lookup table
   if (Dist::GLOBAL_TABLE) dist_lds = (float *)((char *)a.pq_tables + (size_t)blockIdx.x * a.pq_table_bytes);
+  // dense top layers (tiny.hip): this query's row of the distance table and the visited bits of the
+  // table ids, both in LDS; T = 0 when the launch has none (or its layers turned out not to be nested)
+  const uint32_t T = (a.tiny_layers && a.tiny_member[a.tiny_n] == 0u) ? a.tiny_layers : 0u;
+  const bool tiny_lds_row = a.tiny_n <= PH_TINY_LDS_NODES;
+  float *Dl = (float *)(smem + 5 * CAP + 64);
+  uint32_t *Vl = smem + 5 * CAP + 64 + (tiny_lds_row ? a.tiny_stride : 0u);
+  const uint32_t tiny_words = (a.tiny_n + 31u) / 32u;
 
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
@@ -65,11 +72,12 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   }
 
   for (;;) {
-    uint32_t q = 0;
+    uint32_t q = 0, qpos = 0;  // qpos: position in the launch's processing order (row of the dense table)
     if (!a.order) {
       if (lane == 0) q = atomicAdd(a.counter, 1u);
       q = rfl32(q);
       if (q >= a.nq) break;
+      qpos = q;
     } else {
       for (;;) {
         uint32_t p = 0;
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         const uint32_t base = seg_cur * a.seg;
         const uint32_t len = base >= a.nq ? 0u : min(a.seg, a.nq - base);
         if (p < len) {
-          q = a.order[base + p];
+          qpos = base + p;
+          q = a.order[qpos];
           break;
         }
         seg_cur = (seg_cur + 1u) & 7u;
@@ -137,10 +146,25 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       }
       clen = 1;
     }
+    const float *Dg = a.tiny_d + (uint64_t)qpos * a.tiny_stride;  // this query's row of the table
+    if (T) {
+      if (tiny_lds_row)
+        for (uint32_t i = lane; i < a.tiny_n; i += 64) Dl[i] = Dg[i];
+      for (uint32_t i = lane; i < tiny_words; i += 64) Vl[i] = 0u;
+    }
     __syncthreads();
 
     for (uint32_t li = a.knn_mode ? last_layer : a.layer_lo; li < layer_hi && err == ST_OK; li++) {
-      const PhLayerDev L = a.layers[li];
+      PhLayerDev L = a.layers[li];
+      // a dense top layer is walked in table ids: ids, id maps and neighbour rows of the table layer
+      const bool tl = li < T;
+      if (tl) {
+        const PhLayerDev TLy = a.layers[T - 1];
+        L.n_nodes = a.tiny_n;
+        L.nodes = TLy.nodes;
+        L.vec2node = TLy.vec2node;
+        L.neighbors = a.tiny_nbr + a.tiny_off[li];
+      }
       const bool identity = L.vec2node == nullptr;
       // ---- closest_vectors: VectorId -> NodeId, queue = new(cap); merge_pairs  lib.rs:258-266
       uint32_t qlen;
@@ -160,7 +184,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
           if (i < clen) {
             uint32_t vid = Cid[i];
             uint32_t nid = identity ? vid : L.vec2node[vid];
-            if (nid >= L.n_nodes) {  // get_node(v).unwrap() would panic  lib.rs:261
+            if (nid >= L.n_nodes || (tl && !((a.tiny_member[nid] >> li) & 1u))) {  // get_node(v).unwrap() would panic  lib.rs:261
               miss = true;
               nid = 0;
             }
@@ -178,7 +202,10 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
           uint32_t i = lane + 64u * c;
           if (i < clen) {
             uint32_t nid = Qid[i];
-            atomicOr(&vis[nid >> 5], 1u << (nid & 31));
+            if (tl)
+              atomicOr(&Vl[nid >> 5], 1u << (nid & 31));
+            else
+              atomicOr(&vis[nid >> 5], 1u << (nid & 31));
           }
         }
         qlen = clen;
@@ -265,17 +292,24 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         bool fresh = false;
         if (nb < L.n_nodes) {
           uint32_t bit = 1u << (nb & 31);
-          uint32_t old = atomicOr(&vis[nb >> 5], bit);
+          uint32_t old = tl ? atomicOr(&Vl[nb >> 5], bit) : atomicOr(&vis[nb >> 5], bit);
           fresh = !(old & bit);
         }
         const uint64_t fm = __ballot(fresh);
         const uint32_t m = __popcll(fm);
         n_dist += m;
-        uint32_t vid = 0;
-        if (fresh) vid = identity ? nb : L.nodes[nb];
 
-        // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202
-        const float myd = dist.batch(a.dist, fm, vid, lane);
+        // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202 -- in a dense top
+        // layer the value was computed by the tile pass (same bits) and is looked up
+        float myd;
+        if (tl) {
+          myd = 0.f;
+          if (fresh) myd = tiny_lds_row ? Dl[nb] : Dg[nb];
+        } else {
+          uint32_t vid = 0;
+          if (fresh) vid = identity ? nb : L.nodes[nb];
+          myd = dist.batch(a.dist, fm, vid, lane);
+        }
 
         // candidates.merge_pairs(sorted batch)  lib.rs:206,226 / priority_queue.rs:109-144,
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
@@ -375,16 +409,20 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       if (err != ST_OK) break;
 
       // ---- clear this layer's visited bits (queue + spill hold every evaluated node)
+      if (tl) {
+        for (uint32_t i = lane; i < tiny_words; i += 64) Vl[i] = 0u;
+      } else {
 #pragma unroll
-      for (int c = 0; c < CAPC; c++) {
-        uint32_t i = lane + 64u * c;
-        if (i < qlen) vis[(Qid[i] & IDM) >> 5] = 0u;
-      }
-      if (ovf_n) {
-        wait_vm0();
-        for (uint32_t i = lane; i < ovf_n; i += 64) {
-          uint32_t id = __hip_atomic_load(&ovf[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IDM;
-          vis[id >> 5] = 0u;
+        for (int c = 0; c < CAPC; c++) {
+          uint32_t i = lane + 64u * c;
+          if (i < qlen) vis[(Qid[i] & IDM) >> 5] = 0u;
+        }
+        if (ovf_n) {
+          wait_vm0();
+          for (uint32_t i = lane; i < ovf_n; i += 64) {
+            uint32_t id = __hip_atomic_load(&ovf[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IDM;
+            vis[id >> 5] = 0u;
+          }
         }
       }
       wait_vm0();
@@ -536,6 +574,10 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       atomicAdd(&a.totals[0], (unsigned long long)(n_dist - n_dist0));
       atomicAdd(&a.totals[1], (unsigned long long)(n_hops - n_hops0));
     }
+    if (lane == 0 && a.launch_totals) {
+      atomicAdd(&a.launch_totals[0], (unsigned long long)(n_dist - n_dist0));
+      atomicAdd(&a.launch_totals[1], (unsigned long long)(n_hops - n_hops0));
+    }
     if (lane == 0) {
       a.out_len[q] = clen;
       a.status[q] = err;
@@ -571,6 +613,7 @@ static ph_search_fn pick_kernel(int capc, int nv) {
   return nullptr;
 }
 
+// pq_lds: bytes behind the queues -- the PQ lookup table, or the dense-top-layer table row + visited bits
 static size_t lds_bytes(int capc, size_t pq_lds) { return (size_t)(5 * capc * 64 + 64) * 4 + pq_lds; }
 
 uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds) {
@@ -606,7 +649,11 @@ void ph_workspace_free(PhWorkspace &ws) {
   if (ws.pq_tables) hipFree(ws.pq_tables);
   if (ws.ev0) hipEventDestroy(ws.ev0);
   if (ws.ev1) hipEventDestroy(ws.ev1);
+  for (auto &e : ws.evd)
+    if (e) hipEventDestroy(e);
+  if (ws.dtotals) hipFree(ws.dtotals);
   ph_workspace_order_free(ws);
+  ph_tiny_free(ws);
   ws = PhWorkspace();
 }
 
@@ -626,6 +673,8 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
     PH_HIP(hipMalloc(&ws.counter, 512));  // 8 work counters, 64 B apart
     PH_HIP(hipEventCreate(&ws.ev0));
     PH_HIP(hipEventCreate(&ws.ev1));
+    for (auto &e : ws.evd) PH_HIP(hipEventCreate(&e));
+    PH_HIP(hipMalloc(&ws.dtotals, sizeof(unsigned long long) * 2 * PH_MAX_DISPATCH));
   }
   if (ws.n_slots < slots || ws.visited_words < words) {
     if (ws.visited) PH_HIP(hipFree(ws.visited));
@@ -656,10 +705,20 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   return 0;
 }
 
-int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_begin,
-                     bool mark_end) {
+// the wait that orders a descent behind the previous user of this workspace, and the event that
+// starts its clock; the launches of the descent follow on the same stream
+int ph_search_begin(PhWorkspace &ws, hipStream_t stream) {
+  if (ws.timed) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
+  PH_HIP(hipEventRecord(ws.ev0, stream));
+  PH_HIP(hipMemsetAsync(ws.dtotals, 0, sizeof(unsigned long long) * 2 * PH_MAX_DISPATCH, stream));
+  ws.n_dispatch = 0;
+  ws.d_tiny = false;
+  return 0;
+}
+
+int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end) {
   const bool pq = ix->store->codes != nullptr;
-  const size_t pq_lds = (pq && ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store);
+  const size_t pq_lds = pq ? (ph_pq_global_tables() ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
   a.pq_tables = ws.pq_tables;
   a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
@@ -676,12 +735,8 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
-  // launches share the per-wave workspace (visited bitmaps, spill lists): order a launch on
-  // another stream behind the previous one
-  if (ws.timed && mark_begin) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
   PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));
   a.seg = a.order ? (a.nq + 7u) / 8u : 0u;
-  if (mark_begin) PH_HIP(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes(capc, pq_lds), stream, a);
   PH_HIP(hipGetLastError());
   if (mark_end) {

@@ -106,9 +106,11 @@ class VectorStore:
         s._keepalive = keepalive
         return s
 
-    def read(self, first=0, count=None):
+    def read(self, first=0, count=None, out=None):
         count = self.n - first if count is None else count
-        out = np.empty((count, self.dim), dtype=np.float32)
+        if out is None:
+            out = np.empty((count, self.dim), dtype=np.float32)
+        assert out.shape == (count, self.dim) and out.dtype == np.float32 and out.flags.c_contiguous
         check(lib().phnsw_store_read(self._h, first, count, _p(out)))
         return out
 
@@ -248,8 +250,8 @@ class QuantizedHnsw:
         return self.hnsw.vector_count()
 
     # QuantizedHnsw forwards these to the Hnsw over the codes  pq.rs:366-411
-    def improve_index(self, bp=None, progress=None):
-        return self.hnsw.improve_index(bp or self.build_parameters_for_improve_index(), progress)
+    def improve_index(self, bp=None, last_recall=None, progress=None):
+        return self.hnsw.improve_index(bp or self.build_parameters_for_improve_index(), last_recall, progress)
 
     def improve_neighbors_upto(self, upto, bp=None, last_recall=None):
         return self.hnsw.improve_neighbors_upto(upto, bp or self.build_parameters_for_improve_index(), last_recall)
@@ -326,10 +328,12 @@ class Hnsw:
                                      C.byref(added)))
         return added.value
 
-    def improve_index(self, bp=None, progress=None):
+    def improve_index(self, bp=None, last_recall=None, progress=None):
+        """Hnsw::improve_index(bp, last_recall: Option<f32>, progress)  lib.rs:1664-1686"""
         out = C.c_float()
         cb = _lib.PROGRESS_CB(progress) if progress else None
-        check(lib().phnsw_improve_index(self._h, C.byref(bp or self.build_parameters), cb, None, C.byref(out)))
+        check(lib().phnsw_improve_index(self._h, C.byref(bp or self.build_parameters),
+                                        float("nan") if last_recall is None else last_recall, cb, None, C.byref(out)))
         return out.value
 
     def improve_neighbors_upto(self, upto, bp=None, last_recall=None):
@@ -523,6 +527,18 @@ class Hnsw:
         ms = C.c_float()
         check(lib().phnsw_last_search_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def dispatches(self):
+        """the last descent dispatch by dispatch: [{"layers": (lo, hi), "ms", "n_dist", "n_hops"}];
+        entry 0 is the dense-top-layer tile pass (layers (0, 0))"""
+        cap = 32
+        cnt = C.c_uint32()
+        ms = np.zeros(cap, dtype=np.float32)
+        nd, nh = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+        lo, hi = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+        check(lib().phnsw_last_search_dispatches(self._h, cap, C.byref(cnt), _p(ms), _p(nd), _p(nh), _p(lo), _p(hi)))
+        return [{"layers": (int(lo[i]), int(hi[i])), "ms": float(ms[i]), "n_dist": int(nd[i]), "n_hops": int(nh[i])}
+                for i in range(min(cap, cnt.value))]
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

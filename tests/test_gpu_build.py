@@ -90,6 +90,11 @@ def test_link_round_and_recall_parity_on_adopted_graph():
     r_g = gix.improve_index()
     assert r_g == r_o
     layers_equal(gix, oix)
+    # improve_index(bp, Some(last_recall), ..)  lib.rs:1664-1671: the given recall replaces the first estimate
+    r_o2 = oix.improve_index(bp, last_recall=r_o)
+    r_g2 = gix.improve_index(last_recall=r_g)
+    assert r_g2 == r_o2
+    layers_equal(gix, oix)
 
 
 def test_generate_layer_stepwise_parity():

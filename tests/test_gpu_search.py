@@ -97,13 +97,22 @@ def test_search_parity(n, dim, ef, upper, pd):
     cpu = oix.search(queries=q, sp=(ef, upper, pd), stats=True)
     assert_same(gpu, cpu)
     np.testing.assert_array_equal(gpu[3], cpu[3])  # distance evaluations and hops per query
-    # reference summation order: same ids except near-ties, distances within 1e-5 relative
+    # The reference's own summation order (sequential f32, bigvec.rs:48-51) on the same graph: distances
+    # within 1e-5 relative wherever the ids agree, and every slot of the top 10 whose ids differ PROVEN a
+    # near-tie swap: both ids are in the other list inside one group of distances that agree
+    # to 1e-5 relative -- only their order changed.  No tolerance on how many slots may differ otherwise.
     oix.set_sum_mode(oracle.SUM_SEQ)
     seq = oix.search(queries=q, sp=(ef, upper, pd))
-    same = (gpu[0] == seq[0]).mean()
-    assert same > 0.99
     m = gpu[0] == seq[0]
     np.testing.assert_allclose(gpu[1][m], seq[1][m], rtol=1e-5, atol=1e-6)
+    k = min(10, max(1, ef // 2))
+    rep = oracle.tie_swap_report(gpu[0].astype(np.int64), gpu[1], seq[0].astype(np.int64), seq[1], k=k)
+    assert rep["unexplained"] == 0, rep
+    # north_star: recall@10 of the two arithmetic orders within 0.2 % (against exact brute force)
+    gt, _ = oix.bruteforce(q, 10)
+    rec = [np.mean([len(set(r[i, :10].tolist()) & set(gt[i].tolist())) / 10.0 for i in range(len(q))])
+           for r in (gpu[0], seq[0])]
+    assert abs(rec[0] - rec[1]) <= 0.002, rec
 
 
 def test_search_parity_stored_and_exclude():

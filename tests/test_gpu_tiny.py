@@ -1,0 +1,107 @@
+"""Dense top layers (csrc/tiny.hip): the tile pass that evaluates every query against every node
+of the small top layers, and the table-id traversal that consumes it, must reproduce the per-hop
+path bit for bit -- ids, distance bits, lengths, hop and distance counters -- and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parallel_hnsw_amd as ph
+
+pytestmark = pytest.mark.gpu
+
+
+class per_hop_path:
+    """PHNSW_NO_TINY=1: every layer through the per-hop distance batch"""
+
+    def __enter__(self):
+        os.environ["PHNSW_NO_TINY"] = "1"
+
+    def __exit__(self, *a):
+        del os.environ["PHNSW_NO_TINY"]
+
+
+def same(a, b):
+    for x, y in zip(a, b):
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        np.testing.assert_array_equal(x, y)
+
+
+CASES = [
+    # n, dim, metric, sp
+    (6000, 768, ph.METRIC_COSINE_HALF, (104, 104, 8)),   # 3 chunks per lane, exact
+    (6000, 100, ph.METRIC_ONE_MINUS_DOT, (64, 20, 2)),   # one partly filled chunk
+    (3000, 1536, ph.METRIC_COSINE_HALF, (128, 128, 2)),  # 6 chunks per lane: 4 queries per wave
+    (5000, 200, ph.METRIC_L2, (300, 300, 2)),            # L2 chain, queue of 300
+    (700, 64, ph.METRIC_COSINE_HALF, (32, 32, 3)),       # every layer is a dense one
+    (30000, 128, ph.METRIC_COSINE_HALF, (64, 64, 2)),    # table layer of ~2500 nodes: its rows stay in global memory
+]
+
+
+@pytest.mark.parametrize("n,dim,metric,sp", CASES)
+def test_dense_top_layers_match_per_hop_path_and_oracle(n, dim, metric, sp):
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows, metric=metric)
+    bp = ph.BuildParameters(seed=3, max_link_rounds=1)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), bp)
+    assert h._layer(0).node_count() <= 1024  # the shape does have dense top layers
+    q = oracle.synth_rows(2 ** 32, 333, dim)[:, :dim]
+    spx = ph.SearchParameters(*sp)
+    dense = h.search_batch(queries=q, sp=spx, stats=True)
+    with per_hop_path():
+        hop = h.search_batch(queries=q, sp=spx, stats=True)
+    same(dense, hop)
+    # partial tiles: 1, 5 and 33 queries
+    for m in (1, 5, 33):
+        same(h.search_batch(queries=q[:m], sp=spx, stats=True), [x[:m] for x in hop])
+    # Stored queries with exclude (the link-round form)
+    qid = np.arange(0, n, 7, dtype=np.uint64)
+    d2 = h.search_batch(qids=qid, sp=spx, exclude=qid, stats=True)
+    with per_hop_path():
+        h2 = h.search_batch(qids=qid, sp=spx, exclude=qid, stats=True)
+    same(d2, h2)
+    # and the oracle, on the same graph
+    ix = oracle.Index(rows, dim=dim, metric=metric, sum_mode=oracle.SUM_BLOCKED64)
+    for l in h.layers:
+        ix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    ci, cd, cl, cs = ix.search(queries=q, sp=sp, stats=True)
+    np.testing.assert_array_equal(dense[0], ci)
+    np.testing.assert_array_equal(dense[1].view(np.uint32), cd.view(np.uint32))
+    np.testing.assert_array_equal(dense[2], cl)
+    np.testing.assert_array_equal(dense[3], cs)
+
+
+def test_build_is_identical_with_and_without_dense_top_layers():
+    n, dim = 20000, 96
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    bp = ph.BuildParameters(seed=5)
+    a = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), bp)
+    with per_hop_path():
+        b = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), bp)
+    assert a.layer_count() == b.layer_count()
+    for x, y in zip(a.layers, b.layers):
+        np.testing.assert_array_equal(x.nodes, y.nodes)
+        np.testing.assert_array_equal(x.neighbors, y.neighbors)
+
+
+def test_layers_that_are_not_nested_fall_back():
+    """a top layer holding a vector the layer below lacks: the table cannot represent it; the
+    per-hop path runs and reports the reference's panic (lib.rs:261) as PHNSW_E_MISSING_NODE"""
+    n, dim = 64, 16
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    E = ph.EMPTY
+    top = (np.array([5, 9], dtype=np.uint64), np.array([[1, E], [0, E]], dtype=np.uint64))
+    low_nodes = np.array([3, 9, 20, 40], dtype=np.uint64)  # 5 is missing
+    low = (low_nodes, np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]], dtype=np.uint64))
+    h = ph.Hnsw.from_layers(store, [top, low])
+    q = oracle.synth_rows(2 ** 32, 4, dim)[:, :dim]
+    with pytest.raises(ph.PhnswError) as e1:
+        h.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2))
+    with per_hop_path():
+        with pytest.raises(ph.PhnswError) as e2:
+            h.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2))
+    assert e1.value.code == e2.value.code
