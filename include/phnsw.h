@@ -42,7 +42,8 @@ enum {
   PHNSW_E_MISSING_NODE = -4, /* candidate vector absent from a lower layer (lib.rs:261 unwrap) */
   PHNSW_E_OVERFLOW = -5,  /* frontier workspace exhausted even after growth */
   PHNSW_E_NAN = -6,       /* NaN in input vectors (types.rs:86 would panic later) */
-  PHNSW_E_UNSUPPORTED = -7
+  PHNSW_E_UNSUPPORTED = -7,
+  PHNSW_E_NOMEM = -8      /* host allocation failed (a C++ exception never crosses this ABI) */
 };
 
 /* the three Comparator::compare_raw implementations in the reference tree */

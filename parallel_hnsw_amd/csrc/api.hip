@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "phnsw_internal.h"
@@ -27,13 +29,33 @@ int ph_hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? PHNSW_E_NO_DEVICE : PHNSW_E_HIP;
 }
 
+int ph_caught() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    try {
+      ph_set_error("out of host memory");
+    } catch (...) {
+    }
+    return PHNSW_E_NOMEM;
+  } catch (const std::exception &e) {
+    try {
+      ph_set_error("internal error: %s", e.what());
+    } catch (...) {
+    }
+    return PHNSW_E_INVALID;
+  } catch (...) {
+    return PHNSW_E_INVALID;
+  }
+}
+
 extern "C" const char *phnsw_last_error(void) { return g_err.c_str(); }
 
-extern "C" int phnsw_device_count(void) {
+extern "C" int phnsw_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" void phnsw_default_search_params(phnsw_search_params *sp) {
   // SearchParameters::default  src/parameters.rs:10-18
@@ -97,7 +119,7 @@ static int store_check_nan(phnsw_store *s) {
 }
 
 extern "C" int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, int metric, int device,
-                                  phnsw_store **out) {
+                                  phnsw_store **out) try {
   if (!out || !rows || dim == 0 || n == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
     ph_set_error("phnsw_store_create: invalid argument");
     return PHNSW_E_INVALID;
@@ -135,12 +157,12 @@ extern "C" int phnsw_store_create(const float *rows, uint64_t n, uint32_t dim, i
   }
   *out = s;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // more rows for a store that owns its array (the reference grows `Vec<Vec<f32>>` behind the
 // comparator and calls generate / extend on the new ids): the array is reallocated, so no search
 // or build may be running on an index over this store; existing VectorIds keep their rows
-extern "C" int phnsw_store_append(phnsw_store *s, const float *rows, uint64_t count, uint64_t *out_first_id) {
+extern "C" int phnsw_store_append(phnsw_store *s, const float *rows, uint64_t count, uint64_t *out_first_id) try {
   if (!s || !rows || !s->rows || !s->owns_rows || s->n + count >= 0x7FFFFFFFull) {
     ph_set_error("phnsw_store_append: needs an f32 store created by phnsw_store_create* that owns its rows, n < 2^31");
     return PHNSW_E_INVALID;
@@ -173,10 +195,10 @@ extern "C" int phnsw_store_append(phnsw_store *s, const float *rows, uint64_t co
   s->rows = grown;
   s->n += count;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint32_t dim, uint32_t ld, int metric,
-                                         int device, phnsw_store **out) {
+                                         int device, phnsw_store **out) try {
   if (!out || !rows_dev || dim == 0 || n == 0 || ld < dim || (ld % 4) || metric < 0 || metric > 2 ||
       n >= 0x7FFFFFFFull || ((uintptr_t)rows_dev % 16)) {
     ph_set_error("phnsw_store_create_device: invalid argument (ld must be a multiple of 4 >= dim, base 16-byte aligned)");
@@ -199,10 +221,10 @@ extern "C" int phnsw_store_create_device(const float *rows_dev, uint64_t n, uint
   }
   *out = s;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed, int normalize,
-                                            int metric, int device, phnsw_store **out) {
+                                            int metric, int device, phnsw_store **out) try {
   if (!out || dim == 0 || n == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
     ph_set_error("phnsw_store_create_synthetic: invalid argument");
     return PHNSW_E_INVALID;
@@ -232,11 +254,11 @@ extern "C" int phnsw_store_create_synthetic(uint64_t first, uint64_t n, uint32_t
   }
   *out = s;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_store_create_clustered(uint64_t first, uint64_t n, uint32_t dim, uint64_t seed,
                                             uint32_t n_clusters, float noise, int metric, int device,
-                                            phnsw_store **out) {
+                                            phnsw_store **out) try {
   if (!out || dim == 0 || n == 0 || n_clusters == 0 || metric < 0 || metric > 2 || n >= 0x7FFFFFFFull) {
     ph_set_error("phnsw_store_create_clustered: invalid argument");
     return PHNSW_E_INVALID;
@@ -262,10 +284,10 @@ extern "C" int phnsw_store_create_clustered(uint64_t first, uint64_t n, uint32_t
   }
   *out = s;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim, uint32_t *ld, int *metric,
-                                const float **rows_dev) {
+                                const float **rows_dev) try {
   if (!s) return PHNSW_E_INVALID;
   if (n) *n = s->n;
   if (dim) *dim = s->dim;
@@ -273,9 +295,9 @@ extern "C" int phnsw_store_info(const phnsw_store *s, uint64_t *n, uint32_t *dim
   if (metric) *metric = s->metric;
   if (rows_dev) *rows_dev = s->rows;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t count, float *out) {
+extern "C" int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t count, float *out) try {
   if (!s || !out || !s->rows || first + count > s->n) {
     ph_set_error("phnsw_store_read: range out of bounds (or a product-quantised store: use phnsw_pq_read)");
     return PHNSW_E_INVALID;
@@ -285,7 +307,7 @@ extern "C" int phnsw_store_read(const phnsw_store *s, uint64_t first, uint64_t c
   PH_HIP(hipMemcpy2D(out, (size_t)s->dim * 4, s->rows + first * s->ld, (size_t)s->ld * 4, (size_t)s->dim * 4, count,
                      hipMemcpyDeviceToHost));
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" void phnsw_store_destroy(phnsw_store *s) {
   if (!s) return;
@@ -299,7 +321,7 @@ extern "C" void phnsw_store_destroy(phnsw_store *s) {
 }
 
 extern "C" int phnsw_distance_batch(const phnsw_store *s, const float *query, uint64_t query_id, const uint64_t *ids,
-                                    uint64_t k, float *out) {
+                                    uint64_t k, float *out) try {
   if (!s || !ids || !out || (!query && query_id >= s->n) || k > 0xFFFFFFFFull) {
     ph_set_error("phnsw_distance_batch: invalid argument");
     return PHNSW_E_INVALID;
@@ -336,7 +358,7 @@ extern "C" int phnsw_distance_batch(const phnsw_store *s, const float *query, ui
   if (idd) hipFree(idd);
   if (od) hipFree(od);
   return rc;
-}
+} catch (...) { return ph_caught(); }
 
 // ------------------------------------------------------------------ index
 
@@ -421,6 +443,15 @@ int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neig
   return 0;
 }
 
+static std::atomic<uint64_t> g_import_dups{0};
+extern "C" uint64_t phnsw_debug_import_duplicates(void) { return g_import_dups.load(); }
+
+// u64 layer arrays of the ABI -> the device's u32 form, checked.  The crate's link step drops its read
+// lock before it takes the write lock (lib.rs:1123-1147), so an index it built may hold a NodeId twice
+// in one row.  The kernels' visited handling assumes distinct ids per row (the reference itself would
+// evaluate such an id twice and burn a probe on the second, empty, expansion), so the LATER occurrences
+// are dropped here and the row closed up -- the one documented deviation for imported graphs;
+// PHNSW_STRICT_IMPORT=1 refuses such rows instead.
 static int validate_layer(const phnsw_store *s, const uint64_t *nodes, const uint64_t *neighbors, uint64_t n,
                           uint64_t W, std::vector<uint32_t> &nodes32, std::vector<uint32_t> &nb32) {
   if (n == 0 || W == 0 || W > 64 || n >= 0x7FFFFFFFull) {
@@ -428,6 +459,7 @@ static int validate_layer(const phnsw_store *s, const uint64_t *nodes, const uin
                  (unsigned long long)W);
     return PHNSW_E_UNSUPPORTED;
   }
+  const bool strict = getenv("PHNSW_STRICT_IMPORT") != nullptr;
   nodes32.resize(n);
   nb32.resize(n * W);
   for (uint64_t i = 0; i < n; i++) {
@@ -439,11 +471,11 @@ static int validate_layer(const phnsw_store *s, const uint64_t *nodes, const uin
   }
   for (uint64_t i = 0; i < n; i++) {
     bool ended = false;
+    uint64_t o = 0;  // next free slot of the cleaned row
     for (uint64_t k = 0; k < W; k++) {
       uint64_t v = neighbors[i * W + k];
       if (v == PHNSW_EMPTY) {
         ended = true;
-        nb32[i * W + k] = PH_EMPTY32;
         continue;
       }
       if (ended || v >= n) {
@@ -451,21 +483,28 @@ static int validate_layer(const phnsw_store *s, const uint64_t *nodes, const uin
                      (unsigned long long)i);
         return PHNSW_E_INVALID;
       }
-      for (uint64_t j = 0; j < k; j++)
-        if (neighbors[i * W + j] == v) {
-          ph_set_error("neighbor row %llu holds node %llu twice; rows must be duplicate free", (unsigned long long)i,
+      bool dup = false;
+      for (uint64_t j = 0; j < o; j++)
+        if (nb32[i * W + j] == (uint32_t)v) dup = true;
+      if (dup) {
+        if (strict) {
+          ph_set_error("neighbor row %llu holds node %llu twice (PHNSW_STRICT_IMPORT)", (unsigned long long)i,
                        (unsigned long long)v);
           return PHNSW_E_INVALID;
         }
-      nb32[i * W + k] = (uint32_t)v;
+        g_import_dups++;
+        continue;
+      }
+      nb32[i * W + o++] = (uint32_t)v;
     }
+    for (; o < W; o++) nb32[i * W + o] = PH_EMPTY32;
   }
   return 0;
 }
 
 extern "C" int phnsw_index_from_layers(phnsw_store *s, uint32_t layer_count, const uint64_t *node_counts,
                                        const uint64_t *neighborhood_sizes, const uint64_t *const *nodes,
-                                       const uint64_t *const *neighbors, phnsw_index **out) {
+                                       const uint64_t *const *neighbors, phnsw_index **out) try {
   if (!s || !out || layer_count == 0 || layer_count > PH_MAX_LAYERS || !node_counts || !neighborhood_sizes ||
       !nodes || !neighbors) {
     ph_set_error("phnsw_index_from_layers: invalid argument");
@@ -489,7 +528,7 @@ extern "C" int phnsw_index_from_layers(phnsw_store *s, uint32_t layer_count, con
   }
   *out = ix;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   if (!ix) return;
@@ -506,7 +545,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
 
 extern "C" uint32_t phnsw_index_layer_count(const phnsw_index *ix) { return ix ? (uint32_t)ix->layers.size() : 0; }
 
-extern "C" int phnsw_index_layer_info(const phnsw_index *ix, uint32_t lft, uint64_t *node_count, uint64_t *W) {
+extern "C" int phnsw_index_layer_info(const phnsw_index *ix, uint32_t lft, uint64_t *node_count, uint64_t *W) try {
   if (!ix || lft >= ix->layers.size()) {
     ph_set_error("layer %u out of range", lft);
     return PHNSW_E_INVALID;
@@ -514,9 +553,9 @@ extern "C" int phnsw_index_layer_info(const phnsw_index *ix, uint32_t lft, uint6
   if (node_count) *node_count = ix->layers[lft].n_nodes;
   if (W) *W = ix->layers[lft].W;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_index_layer_read(const phnsw_index *ix, uint32_t lft, uint64_t *nodes, uint64_t *neighbors) {
+extern "C" int phnsw_index_layer_read(const phnsw_index *ix, uint32_t lft, uint64_t *nodes, uint64_t *neighbors) try {
   if (!ix || lft >= ix->layers.size()) {
     ph_set_error("layer %u out of range", lft);
     return PHNSW_E_INVALID;
@@ -534,7 +573,7 @@ extern "C" int phnsw_index_layer_read(const phnsw_index *ix, uint32_t lft, uint6
     for (size_t i = 0; i < t.size(); i++) neighbors[i] = t[i] == PH_EMPTY32 ? PHNSW_EMPTY : t[i];
   }
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // ------------------------------------------------------------------ search
 
@@ -724,7 +763,7 @@ extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *que
                                          const uint32_t *qids_dev, uint64_t nq, const phnsw_search_params *sp,
                                          uint32_t upto_layers, const uint32_t *exclude_dev, uint32_t *out_ids_dev,
                                          float *out_d_dev, uint32_t *out_len_dev, uint32_t *out_stats_dev,
-                                         uint32_t *status_dev, void *stream) {
+                                         uint32_t *status_dev, void *stream) try {
   int rc = check_sp(ix, sp);
   if (rc) return rc;
   if ((!queries_dev && !qids_dev) || !out_ids_dev || !out_d_dev || !out_len_dev || !status_dev ||
@@ -736,23 +775,23 @@ extern "C" int phnsw_search_batch_device(const phnsw_index *ix, const float *que
   PH_HIP(hipSetDevice(ix->store->device));
   return ph_search_device(ix, queries_dev, ldq, qids_dev, nq, sp, upto_layers, exclude_dev, out_ids_dev, out_d_dev,
                           out_len_dev, out_stats_dev, status_dev, 0, 0, (hipStream_t)stream);
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_debug_layer_pos(phnsw_index *ix, uint32_t lft, uint32_t *out_host) {
+extern "C" int phnsw_debug_layer_pos(phnsw_index *ix, uint32_t lft, uint32_t *out_host) try {
   if (lft >= ix->layers.size() || !ix->layers[lft].pos) return PHNSW_E_INVALID;
   PH_HIP(hipMemcpy(out_host, ix->layers[lft].pos, (size_t)ix->layers[lft].n_nodes * 4, hipMemcpyDeviceToHost));
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_debug_set_order(phnsw_index *ix, const uint32_t *order_dev, uint64_t n) {
+extern "C" int phnsw_debug_set_order(phnsw_index *ix, const uint32_t *order_dev, uint64_t n) try {
   ix->dbg_order = order_dev;
   ix->dbg_order_n = n;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // distance evaluations and hops of every search launched on this index since it was created --
 // build rounds included: the basis of the build's algorithmic bytes
-extern "C" int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uint64_t *n_hops) {
+extern "C" int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uint64_t *n_hops) try {
   if (!ix) return PHNSW_E_INVALID;
   unsigned long long h[2] = {0, 0};
   if (ix->totals) {
@@ -763,9 +802,9 @@ extern "C" int phnsw_index_counters(const phnsw_index *ix, uint64_t *n_dist, uin
   if (n_dist) *n_dist = h[0];
   if (n_hops) *n_hops = h[1];
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
+extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) try {
   if (!ix || !ms) return PHNSW_E_INVALID;
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   std::lock_guard<std::mutex> g(mix->ws_mutex);
@@ -777,7 +816,7 @@ extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
   PH_HIP(hipEventSynchronize(ws.ev1));
   PH_HIP(hipEventElapsedTime(ms, ws.ev0, ws.ev1));
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // the last descent on this index, dispatch by dispatch: entry 0 = the dense-top-layer kernels
 // (layer_lo = layer_hi = 0, no counters; 0 ms when the descent had none), then one entry per launch
@@ -785,7 +824,7 @@ extern "C" int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms) {
 // time includes the key sort in front of it) and the distance evaluations / hops it performed
 extern "C" int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap, uint32_t *count, float *ms,
                                             uint64_t *n_dist, uint64_t *n_hops, uint32_t *layer_lo,
-                                            uint32_t *layer_hi) {
+                                            uint32_t *layer_hi) try {
   if (!ix || !count) return PHNSW_E_INVALID;
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   std::lock_guard<std::mutex> g(mix->ws_mutex);
@@ -810,7 +849,7 @@ extern "C" int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap,
     if (layer_hi) layer_hi[i] = i ? ws.d_hi[i - 1] : 0;
   }
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // host-pointer search: stage, launch, grow the spill workspace and retry the few queries
 // that overflowed it, convert u32 -> u64 ids
@@ -938,28 +977,28 @@ static int search_host(const phnsw_index *ix, const float *queries, const uint64
 
 extern "C" int phnsw_search_batch(const phnsw_index *ix, const float *queries, uint64_t nq,
                                   const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
-                                  uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+                                  uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
   if (!queries && nq) {
     ph_set_error("phnsw_search_batch: queries is NULL");
     return PHNSW_E_INVALID;
   }
   return search_host(ix, queries, nullptr, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_search_batch_stored(const phnsw_index *ix, const uint64_t *qids, uint64_t nq,
                                          const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
-                                         uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+                                         uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
   if (!qids && nq) {
     ph_set_error("phnsw_search_batch_stored: qids is NULL");
     return PHNSW_E_INVALID;
   }
   return search_host(ix, nullptr, qids, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
-}
+} catch (...) { return ph_caught(); }
 
 // Hnsw::knn  src/lib.rs:905-928: queue of 3k seeded with (self, 0.0), closest_nodes on the
 // bottom layer, drop self, take k
 extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids, float *out_d,
-                         uint64_t *out_len) {
+                         uint64_t *out_len) try {
   if (!ix || ix->layers.empty() || k == 0 || k * 3 > 1024) {
     ph_set_error("phnsw_knn: k must be 1..341");
     return PHNSW_E_INVALID;
@@ -989,7 +1028,7 @@ extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth
     }
   }
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // Hnsw::threshold_nn  src/lib.rs:930-962: per bottom-layer node a queue seeded with
 // (self, 0.0) that doubles (resize_capacity) until its last entry reaches the threshold;
@@ -997,7 +1036,7 @@ extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth
 // queue may grow to 1024 entries on the device.
 extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,
                                   uint64_t initial_search_depth, uint64_t max_out, uint64_t *out_ids, float *out_d,
-                                  uint64_t *out_len) {
+                                  uint64_t *out_len) try {
   if (!ix || ix->layers.empty() || !out_ids || !out_d || !out_len || initial_search_depth == 0 ||
       initial_search_depth > 1024 || probe_depth == 0 || max_out == 0) {
     ph_set_error("phnsw_threshold_nn: initial_search_depth must be 1..1024, probe_depth >= 1");
@@ -1070,4 +1109,4 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (olen) hipFree(olen);
   if (ostat) hipFree(ostat);
   return rc;
-}
+} catch (...) { return ph_caught(); }

@@ -161,7 +161,7 @@ static thread_local float g_bf_gemm_ms = 0.f;
 
 // everything on the device: queries_dev [nq][ldq], outputs [nq][k] (u32 ids, f32 distances)
 extern "C" int phnsw_bruteforce_topk_device(const phnsw_store *s, const float *queries_dev, uint32_t ldq, uint64_t nq,
-                                            uint32_t k, uint32_t *out_ids_dev, float *out_d_dev, void *stream) {
+                                            uint32_t k, uint32_t *out_ids_dev, float *out_d_dev, void *stream) try {
   if (!s || !s->rows || !queries_dev || !out_ids_dev || !out_d_dev || k == 0 || k > BF_KMAX || k > s->n ||
       nq == 0 || nq > 0xFFFFFFFFull || ldq < s->ld || (ldq % 4) || s->metric == PHNSW_METRIC_L2) {
     ph_set_error("phnsw_bruteforce_topk: need an f32 store with a dot-product metric, 1 <= k <= %d, ldq %% 4 == 0",
@@ -217,7 +217,7 @@ extern "C" int phnsw_bruteforce_topk_device(const phnsw_store *s, const float *q
   hipFree(scores);
   hipFree(best);
   return rc;
-}
+} catch (...) { return ph_caught(); }
 
 // ---- coarse cells for the locality schedule (phnsw_internal.h PhLayerHost::pos) ----
 __global__ void ph_gather_rows_f32_kernel(const float *rows, uint32_t ld, const uint32_t *ids, uint32_t stride,
@@ -416,7 +416,7 @@ int ph_layer_anchor_pos(const phnsw_store *cs, PhLayerHost &L) {
 extern "C" float phnsw_bruteforce_last_gemm_ms(void) { return g_bf_gemm_ms; }
 
 extern "C" int phnsw_bruteforce_topk(const phnsw_store *s, const float *queries, uint64_t nq, uint32_t k,
-                                     uint64_t *out_ids, float *out_d) {
+                                     uint64_t *out_ids, float *out_d) try {
   if (!s || !queries || !out_ids || !out_d || nq == 0) {
     ph_set_error("phnsw_bruteforce_topk: invalid argument");
     return PHNSW_E_INVALID;
@@ -445,4 +445,4 @@ extern "C" int phnsw_bruteforce_topk(const phnsw_store *s, const float *queries,
   if (oid) hipFree(oid);
   if (od) hipFree(od);
   return rc;
-}
+} catch (...) { return ph_caught(); }

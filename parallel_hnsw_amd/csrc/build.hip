@@ -1497,82 +1497,82 @@ static int enter(const phnsw_index *ix) {
 }
 
 extern "C" int phnsw_generate_layer(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
-                                    const phnsw_build_params *bp) {
+                                    const phnsw_build_params *bp) try {
   PH_TRY(enter(ix));
   return generate_layer_impl(ix, vids, n, neighborhood_size, bp);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_link_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
-                                uint64_t link_count, uint64_t *out_added) {
+                                uint64_t link_count, uint64_t *out_added) try {
   PH_TRY(enter(ix));
   if (!sp) return PHNSW_E_INVALID;
   return link_layer_impl(ix, layer_from_top, sp, link_count, out_added);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_stochastic_recall_at(phnsw_index *ix, uint32_t layer_from_top,
-                                          const phnsw_optimization_params *op, float *out_recall) {
+                                          const phnsw_optimization_params *op, float *out_recall) try {
   PH_TRY(enter(ix));
   if (!op || !out_recall) return PHNSW_E_INVALID;
   return recall_impl(ix, layer_from_top, op, out_recall);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, const phnsw_build_params *bp,
-                                            float last_recall, float *out_recall) {
+                                            float last_recall, float *out_recall) try {
   PH_TRY(enter(ix));
   if (!bp || !out_recall) return PHNSW_E_INVALID;
   return improve_neighbors_upto_impl(ix, upto, bp, last_recall, out_recall);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp, float last_recall,
-                                   phnsw_progress_cb cb, void *user, float *out_recall) {
+                                   phnsw_progress_cb cb, void *user, float *out_recall) try {
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
   return improve_index_impl(ix, bp, last_recall, cb, user, out_recall);
-}
+} catch (...) { return ph_caught(); }
 
 // ---- phase entry points for multi-GPU drivers (device buffers, u32 ids) ----
 extern "C" int phnsw_layer_begin(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
-                                 const phnsw_build_params *bp, int *needs_phases) {
+                                 const phnsw_build_params *bp, int *needs_phases) try {
   PH_TRY(enter(ix));
   if (!needs_phases) return PHNSW_E_INVALID;
   return layer_begin_impl(ix, vids, n, neighborhood_size, bp, needs_phases);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_layer_init_search_device(phnsw_index *ix, const phnsw_build_params *bp, uint64_t first,
-                                              uint64_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len) {
+                                              uint64_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len) try {
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
   return layer_init_search_impl(ix, bp, (uint32_t)first, (uint32_t)count, out_ids, out_d, out_len);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_layer_seed_device(phnsw_index *ix, const phnsw_build_params *bp, const uint32_t *init_ids,
                                        const float *init_d, const uint32_t *init_len, uint64_t first, uint64_t count,
-                                       uint32_t *out_rows, float *out_rows_d) {
+                                       uint32_t *out_rows, float *out_rows_d) try {
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
   return layer_seed_impl(ix, bp, init_ids, init_d, init_len, (uint32_t)first, (uint32_t)count, out_rows, out_rows_d);
-}
-extern "C" int phnsw_layer_finish_device(phnsw_index *ix, const uint32_t *rows, const float *rows_d) {
+} catch (...) { return ph_caught(); }
+extern "C" int phnsw_layer_finish_device(phnsw_index *ix, const uint32_t *rows, const float *rows_d) try {
   PH_TRY(enter(ix));
   return layer_finish_impl(ix, rows, rows_d);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_link_search_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
                                         uint64_t link_count, uint64_t first, uint64_t count, uint32_t *out_ids,
-                                        float *out_d, uint32_t *out_len) {
+                                        float *out_d, uint32_t *out_len) try {
   PH_TRY(enter(ix));
   if (!sp) return PHNSW_E_INVALID;
   return link_search_impl(ix, layer_from_top, sp, link_count, (uint32_t)first, (uint32_t)count, out_ids, out_d, out_len);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_link_apply_device(phnsw_index *ix, uint32_t layer_from_top, uint64_t link_count,
-                                       const uint32_t *ids, const float *d, const uint32_t *len, uint64_t *out_added) {
+                                       const uint32_t *ids, const float *d, const uint32_t *len, uint64_t *out_added) try {
   PH_TRY(enter(ix));
   return link_apply_impl(ix, layer_from_top, link_count, ids, d, len, out_added);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
-                                 uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection) {
+                                 uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection) try {
   PH_TRY(enter(ix));
   if (!op || !out_hits) return PHNSW_E_INVALID;
   return recall_hits_impl(ix, layer_from_top, op, first, count, out_hits, out_selection);
-}
-extern "C" int phnsw_index_create(phnsw_store *s, const phnsw_build_params *bp, phnsw_index **out) {
+} catch (...) { return ph_caught(); }
+extern "C" int phnsw_index_create(phnsw_store *s, const phnsw_build_params *bp, phnsw_index **out) try {
   if (!s || !out) return PHNSW_E_INVALID;
   PH_HIP(hipSetDevice(s->device));
   phnsw_index *ix = new phnsw_index();
@@ -1584,11 +1584,11 @@ extern "C" int phnsw_index_create(phnsw_store *s, const phnsw_build_params *bp, 
     phnsw_default_build_params(&ix->bp);
   *out = ix;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 // the deterministic id shuffle of phnsw_build (lib.rs:832-833) and its layer sizes
 // (calculate_partitions lib.rs:1883-1899) for drivers that run the phases themselves
 extern "C" int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_build_params *bp, uint64_t *shuffled,
-                                uint64_t *layer_sizes, uint32_t max_layers, uint32_t *layer_count) {
+                                uint64_t *layer_sizes, uint32_t max_layers, uint32_t *layer_count) try {
   if (!vids || !bp || !shuffled || !layer_sizes || !layer_count || n == 0 || bp->order < 2) {
     ph_set_error("phnsw_build_plan: invalid argument");
     return PHNSW_E_INVALID;
@@ -1600,7 +1600,7 @@ extern "C" int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_bu
   for (size_t i = 0; i < parts.size(); i++) layer_sizes[i] = parts[i];
   *layer_count = (uint32_t)parts.size();
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // Hnsw::generate  lib.rs:825-893
 static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
@@ -1648,15 +1648,15 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
 }
 
 extern "C" int phnsw_build(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
-                           phnsw_progress_cb cb, void *user, phnsw_index **out) {
+                           phnsw_progress_cb cb, void *user, phnsw_index **out) try {
   int rc = build_impl(s, vids, n, bp, cb, user, out);
   ph_pool_trim();  // scratch of the rounds goes back to the driver
   return rc;
-}
+} catch (...) { return ph_caught(); }
 
 // Hnsw::extend_layer  src/lib.rs:1039-1068: the vectors join the layer with empty rows, old rows
 // are renumbered; a vector that is already in the layer is an error (the reference panics, :1797)
-extern "C" int phnsw_extend_layer(phnsw_index *ix, uint32_t layer_from_top, const uint64_t *vids, uint64_t n) {
+extern "C" int phnsw_extend_layer(phnsw_index *ix, uint32_t layer_from_top, const uint64_t *vids, uint64_t n) try {
   PH_TRY(enter(ix));
   if (layer_from_top >= ix->layers.size() || (!vids && n)) {
     ph_set_error("extend_layer: layer %u out of range", layer_from_top);
@@ -1676,33 +1676,33 @@ extern "C" int phnsw_extend_layer(phnsw_index *ix, uint32_t layer_from_top, cons
     return PHNSW_E_INVALID;
   }
   return extend_layer_impl(ix, layer_from_top, v);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_promote_at_layer(phnsw_index *ix, uint32_t layer_from_top, const phnsw_build_params *bp,
-                                      int *out_promoted) {
+                                      int *out_promoted) try {
   PH_TRY(enter(ix));
   if (!bp || !out_promoted) return PHNSW_E_INVALID;
   return promote_at_layer_impl(ix, layer_from_top, bp, out_promoted);
-}
+} catch (...) { return ph_caught(); }
 
 // phase API: the searches of promote_at_layer for a node range, then the promotion itself from
 // the all-gathered flags
 extern "C" int phnsw_discover_hits_device(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
-                                          uint64_t first, uint64_t count, uint32_t *out_hit) {
+                                          uint64_t first, uint64_t count, uint32_t *out_hit) try {
   PH_TRY(enter(ix));
   if (!sp || !out_hit) return PHNSW_E_INVALID;
   return discover_hits_impl(ix, layer_from_top, sp, (uint32_t)first, (uint32_t)count, out_hit);
-}
+} catch (...) { return ph_caught(); }
 extern "C" int phnsw_promote_at_layer_hits_device(phnsw_index *ix, uint32_t layer_from_top,
                                                   const phnsw_build_params *bp, const uint32_t *hit,
-                                                  int *out_promoted) {
+                                                  int *out_promoted) try {
   PH_TRY(enter(ix));
   if (!bp || !hit || !out_promoted) return PHNSW_E_INVALID;
   return promote_at_layer_impl(ix, layer_from_top, bp, out_promoted, hit);
-}
+} catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_discover_unreachable(phnsw_index *ix, uint32_t layer_from_top, const phnsw_search_params *sp,
-                                          uint64_t *out_vecs, uint64_t *out_count) {
+                                          uint64_t *out_vecs, uint64_t *out_count) try {
   PH_TRY(enter(ix));
   if (!sp || !out_vecs || !out_count) return PHNSW_E_INVALID;
   std::vector<uint32_t> v;
@@ -1710,4 +1710,4 @@ extern "C" int phnsw_discover_unreachable(phnsw_index *ix, uint32_t layer_from_t
   for (size_t i = 0; i < v.size(); i++) out_vecs[i] = v[i];
   *out_count = v.size();
   return 0;
-}
+} catch (...) { return ph_caught(); }

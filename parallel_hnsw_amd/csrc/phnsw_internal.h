@@ -20,6 +20,9 @@
 #define PH_TINY_MAX_LAYERS 8
 
 void ph_set_error(const char *fmt, ...);
+// every extern "C" entry point is a function-try-block ending in `catch (...) { return ph_caught(); }`:
+// nothing unwinds across the ABI (phnsw.h), a C++ exception becomes a status + message
+int ph_caught() noexcept;
 int ph_hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define PH_HIP(x)                                                       \
   do {                                                                  \

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void ph_pq_rerank_kernel(PhDistArgs full, const
     if (rc__) return rc__; \
   } while (0)
 
-extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) {
+extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) try {
   if (!full || !out || full->codes || !full->rows || m == 0 || ksub == 0 || ksub > 256 || (m % 4) ||
       (full->dim % m) || ksub > full->n) {
     ph_set_error("phnsw_store_create_pq: need an f32 store, m %% 4 == 0, dim %% m == 0, 1 <= ksub <= min(256, n)");
@@ -186,7 +186,7 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   }
   *out = s;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // How the per-query lookup table T[m][ksub] is stored.  0: f32, the
 // reference arithmetic.  1: every entry rounded once to IEEE half.  2: 8-bit entries
@@ -194,7 +194,7 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
 // bias + scale * (exact integer sum), bias = sum of the row minima.  Modes 1 and 2 change the
 // quantised distances; a graph must be built and searched in the same mode.  The oracle mirrors
 // every mode bit for bit.
-extern "C" int phnsw_pq_set_table_mode(phnsw_store *s, int mode) {
+extern "C" int phnsw_pq_set_table_mode(phnsw_store *s, int mode) try {
   if (!s || !s->codes || mode < 0 || mode > 2) {
     ph_set_error("phnsw_pq_set_table_mode: needs a product-quantised store and mode 0 (f32), 1 (f16) or 2 (8-bit)");
     return PHNSW_E_INVALID;
@@ -205,12 +205,12 @@ extern "C" int phnsw_pq_set_table_mode(phnsw_store *s, int mode) {
   }
   s->pq_table_f16 = (uint32_t)mode;
   return 0;
-}
-extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) { return phnsw_pq_set_table_mode(s, on ? 1 : 0); }
+} catch (...) { return ph_caught(); }
+extern "C" int phnsw_pq_set_table_f16(phnsw_store *s, int on) try { return phnsw_pq_set_table_mode(s, on ? 1 : 0); } catch (...) { return ph_caught(); }
 
 // Quantizer::quantize  pq.rs:61-71 for arbitrary vectors (exact nearest centroid per sub-space,
 // ties to the smaller centroid id) and Quantizer::reconstruct  pq.rs:73-81
-extern "C" int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64_t n, uint8_t *out_codes) {
+extern "C" int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64_t n, uint8_t *out_codes) try {
   if (!s || !s->codes || !rows || !out_codes) {
     ph_set_error("phnsw_pq_quantize: needs a product-quantised store, rows and an output buffer");
     return PHNSW_E_INVALID;
@@ -234,9 +234,9 @@ extern "C" int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64
   if (cd) hipFree(cd);
   if (e != hipSuccess) return ph_hip_fail(e, "pq quantize", __FILE__, __LINE__);
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, uint64_t n, float *out_rows) {
+extern "C" int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, uint64_t n, float *out_rows) try {
   if (!s || !s->codes || !codes || !out_rows) {
     ph_set_error("phnsw_pq_reconstruct: needs a product-quantised store, codes and an output buffer");
     return PHNSW_E_INVALID;
@@ -260,9 +260,9 @@ extern "C" int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, 
   if (cd) hipFree(cd);
   if (e != hipSuccess) return ph_hip_fail(e, "pq reconstruct", __FILE__, __LINE__);
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) {
+extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) try {
   if (!s || !s->codes) {
     ph_set_error("not a product-quantised store");
     return PHNSW_E_INVALID;
@@ -271,9 +271,9 @@ extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, 
   if (ksub) *ksub = s->pq_ksub;
   if (dsub) *dsub = s->pq_dsub;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook) {
+extern "C" int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebook) try {
   if (!s || !s->codes) {
     ph_set_error("not a product-quantised store");
     return PHNSW_E_INVALID;
@@ -283,14 +283,14 @@ extern "C" int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebo
   if (codebook)
     PH_HIP(hipMemcpy(codebook, s->codebook, (size_t)s->pq_m * s->pq_ksub * s->pq_dsub * 4, hipMemcpyDeviceToHost));
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // QuantizedHnsw::search  pq.rs:346-364 for a batch: (optionally quantise the query like the
 // reference :351-352, default = asymmetric: the raw query meets the codes), search the graph
 // over the code rows, re-rank with the full-precision store, sort by (d, id).
 extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *full, const float *queries, uint64_t nq,
                                      const phnsw_search_params *sp, int quantize_query, uint64_t *out_ids,
-                                     float *out_d, uint64_t *out_len, uint64_t *out_stats) {
+                                     float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
   if (!ix || !full || !queries || !sp || !out_ids || !out_d || !out_len || !ix->store->codes || !full->rows ||
       full->n != ix->store->n || full->dim != ix->store->dim || nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 ||
       sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
@@ -384,14 +384,14 @@ extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *f
   for (void *p : {(void *)qd, (void *)qq, (void *)od, (void *)oid, (void *)olen, (void *)ost, (void *)ostat, (void *)qcodes})
     if (p) hipFree(p);
   return rc;
-}
+} catch (...) { return ph_caught(); }
 
 // zero-copy form of phnsw_pq_search_batch (asymmetric queries): search kernel + re-rank
 // kernel enqueued on `stream`, u32 ids, no synchronisation.
 extern "C" int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_store *full, const float *queries_dev,
                                             uint32_t ldq, uint64_t nq, const phnsw_search_params *sp,
                                             uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
-                                            uint32_t *out_stats_dev, uint32_t *status_dev, void *stream) {
+                                            uint32_t *out_stats_dev, uint32_t *status_dev, void *stream) try {
   if (!ix || !full || !queries_dev || !sp || !out_ids_dev || !out_d_dev || !out_len_dev || !status_dev ||
       !ix->store->codes || !full->rows || full->n != ix->store->n || full->dim != ix->store->dim ||
       nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0 ||
@@ -421,4 +421,4 @@ extern "C" int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_s
   }
   PH_HIP(hipGetLastError());
   return 0;
-}
+} catch (...) { return ph_caught(); }

@@ -69,12 +69,18 @@ static int write_file(const std::string &path, const void *data, size_t bytes) {
     return PHNSW_E_INVALID;
   }
   size_t w = bytes ? fwrite(data, 1, bytes, f) : 0;
-  fclose(f);
-  if (w != bytes) {
+  const int closed = fclose(f);  // a write error may only surface when the buffer is flushed
+  if (w != bytes || closed != 0) {
     ph_set_error("short write to %s", path.c_str());
     return PHNSW_E_INVALID;
   }
   return 0;
+}
+
+// std::fs::create_dir_all  serialize.rs:41-47
+static void create_dir_all(const std::string &dir) {
+  for (size_t i = 1; i <= dir.size(); i++)
+    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0777);
 }
 
 static int read_file(const std::string &path, std::string &out) {
@@ -122,7 +128,7 @@ static bool parse_sp(const std::string &s, size_t from, phnsw_search_params *p) 
   return true;
 }
 
-extern "C" int phnsw_index_serialize(const phnsw_index *ix, const char *path) {
+extern "C" int phnsw_index_serialize(const phnsw_index *ix, const char *path) try {
   if (!ix || !path) {
     ph_set_error("phnsw_index_serialize: invalid argument");
     return PHNSW_E_INVALID;
@@ -130,7 +136,7 @@ extern "C" int phnsw_index_serialize(const phnsw_index *ix, const char *path) {
   const phnsw_store *s = ix->store;
   PH_HIP(hipSetDevice(s->device));
   std::string dir(path);
-  mkdir(dir.c_str(), 0777);  // create_dir_all (one level is what the tests need; parents must exist)
+  create_dir_all(dir);
   if (!exists(dir)) {
     ph_set_error("cannot create directory %s", dir.c_str());
     return PHNSW_E_INVALID;
@@ -183,10 +189,10 @@ extern "C" int phnsw_index_serialize(const phnsw_index *ix, const char *path) {
     if (rc) return rc;
   }
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
 // deserialize_hnsw  serialize.rs:126-209 against an existing store (the C::Params role)
-extern "C" int phnsw_index_deserialize(phnsw_store *s, const char *path, phnsw_index **out) {
+extern "C" int phnsw_index_deserialize(phnsw_store *s, const char *path, phnsw_index **out) try {
   if (!s || !path || !out) {
     ph_set_error("phnsw_index_deserialize: invalid argument");
     return PHNSW_E_INVALID;
@@ -234,6 +240,12 @@ extern "C" int phnsw_index_deserialize(phnsw_store *s, const char *path, phnsw_i
       ph_set_error("%s/layer.meta%s: malformed", path, suffix.c_str());
       return PHNSW_E_INVALID;
     }
+    // a corrupt or crafted meta file must not size an allocation: same limits as phnsw_index_from_layers
+    if (!(nc >= 1.0 && nc < 2147483647.0) || !(w >= 1.0 && w <= 64.0) || nc != (double)(uint64_t)nc || w != (double)(uint64_t)w) {
+      ph_set_error("%s/layer.meta%s: node_count %.17g / neighborhood_size %.17g out of range (1..2^31-2, 1..64)", path,
+                   suffix.c_str(), nc, w);
+      return PHNSW_E_INVALID;
+    }
     counts[i] = (uint64_t)nc;
     widths[i] = (uint64_t)w;
     rc = read_file(dir + "/layer.nodes" + suffix, raw);
@@ -268,10 +280,10 @@ extern "C" int phnsw_index_deserialize(phnsw_store *s, const char *path, phnsw_i
   if (rc) return rc;
   (*out)->bp = bp;
   return 0;
-}
+} catch (...) { return ph_caught(); }
 
-extern "C" int phnsw_index_build_params(const phnsw_index *ix, phnsw_build_params *bp) {
+extern "C" int phnsw_index_build_params(const phnsw_index *ix, phnsw_build_params *bp) try {
   if (!ix || !bp) return PHNSW_E_INVALID;
   *bp = ix->bp;
   return 0;
-}
+} catch (...) { return ph_caught(); }

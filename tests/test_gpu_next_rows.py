@@ -90,6 +90,21 @@ def test_serialize_layout_and_roundtrip(tmp_path):
     h2 = ph.Hnsw.deserialize(p, store)
     assert h2.layer_count() == L
     assert h2.build_parameters.order == 6 and h2.build_parameters.neighborhood_size == 8
+    # create_dir_all (serialize.rs:41-47): parents are made on the way
+    deep = tmp_path / "a" / "b" / "index"
+    h.serialize(deep)
+    assert ph.Hnsw.deserialize(deep, store).layer_count() == L
+    # a corrupt / crafted layer.meta must be refused before it sizes anything (no exception may cross the ABI)
+    good = open(deep / "layer.meta.0").read()
+    for bad in ('{"node_count":18446744073709551615,"neighborhood_size":16}', '{"node_count":1e300,"neighborhood_size":16}',
+                '{"node_count":1500,"neighborhood_size":0}', '{"node_count":1500,"neighborhood_size":2305843009213693952}',
+                '{"node_count":-5,"neighborhood_size":16}', '{"node_count":2.5,"neighborhood_size":16}'):
+        open(deep / "layer.meta.0", "w").write(bad)
+        with pytest.raises(ph.PhnswError) as e:
+            ph.Hnsw.deserialize(deep, store)
+        assert e.value.code in (-1, -7), bad
+    open(deep / "layer.meta.0", "w").write(good)
+    assert ph.Hnsw.deserialize(deep, store).layer_count() == L
     q = oracle.synth_rows(2 ** 32, 50, dim)[:, :dim]
     a = h.search_batch(queries=q, sp=ph.SearchParameters(64, 64, 2))
     c = h2.search_batch(queries=q, sp=ph.SearchParameters(64, 64, 2))

@@ -3,6 +3,8 @@ seeded inputs and the same graph.  Integer results (ids, lengths, hop / distance
 must be identical; distances are compared bit-exactly against the oracle in the kernel's
 summation order (ORC_SUM_BLOCKED64) and within 1e-5 relative against the reference's
 sequential order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -199,8 +201,20 @@ def test_edge_cases():
         h.search(ph.Stored(4), ph.SearchParameters(10, 10, 0))
     with pytest.raises(ph.PhnswError):
         ph.Hnsw.from_layers(store, [(np.array([1, 0], dtype=np.uint64), np.full((2, 3), EMPTY, dtype=np.uint64))])
-    with pytest.raises(ph.PhnswError):
-        ph.Hnsw.from_layers(store, [(np.array([0, 1], dtype=np.uint64), np.array([[1, 1, EMPTY], [0, EMPTY, EMPTY]], dtype=np.uint64))])
+    # a NodeId twice in one row -- the crate's racy link step can write that (lib.rs:1123-1147): the later
+    # occurrence is dropped on import (documented deviation), PHNSW_STRICT_IMPORT refuses the row
+    dup_layers = [(np.array([0, 1, 2], dtype=np.uint64),
+                   np.array([[1, 1, 2], [0, 2, 0], [1, EMPTY, EMPTY]], dtype=np.uint64))]
+    hd = ph.Hnsw.from_layers(store, dup_layers)
+    np.testing.assert_array_equal(hd._layer(0).neighbors,
+                                  np.array([[1, 2, EMPTY], [0, 2, EMPTY], [1, EMPTY, EMPTY]], dtype=np.uint64))
+    assert len(hd.search(ph.Stored(0), ph.SearchParameters(10, 10, 2))) == 3
+    os.environ["PHNSW_STRICT_IMPORT"] = "1"
+    try:
+        with pytest.raises(ph.PhnswError):
+            ph.Hnsw.from_layers(store, dup_layers)
+    finally:
+        del os.environ["PHNSW_STRICT_IMPORT"]
     with pytest.raises(ph.PhnswError):
         ph.VectorStore(np.array([[np.nan, 0, 0]], dtype=np.float32))
 
