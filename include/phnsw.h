@@ -264,6 +264,11 @@ int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_opti
  * reconstruction, so code-vs-code distances are symmetric).  m % 4 == 0, dim % m == 0,
  * ksub <= 256, m*ksub*4 bytes must fit the LDS. */
 int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out);
+/* the same with k-means codebooks (the reference's own k-means is dead code,
+ * pq.rs:215-259): kmeans_iters Lloyd iterations from the random_centroids start, trained on the first
+ * min(n, sample) vectors of the seeded shuffle (sample 0 = all); kmeans_iters 0 == phnsw_store_create_pq */
+int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
+                                 uint32_t kmeans_iters, uint64_t sample, phnsw_store **out);
 int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);
 /* storage of the per-query lookup table: 0 = f32 (reference arithmetic), 1 = IEEE half entries,
  * 2 = 8-bit entries with a per-query scale (integer sums; fewest L2 requests per hop).  Modes 1

@@ -158,6 +158,8 @@ def lib():
         L.orc_first_touch.restype = None
         L.orc_pq_create.restype = i32
         L.orc_pq_create.argtypes = [vp, u64, u32, u32, u32, u32, u64, vp, vp, i32]
+        L.orc_pq_create_kmeans.restype = i32
+        L.orc_pq_create_kmeans.argtypes = [vp, u64, u32, u32, u32, u32, u64, u32, u64, vp, vp, i32]
         L.orc_index_set_pq.argtypes = [vp, vp, vp, u32, u32, u32]
         L.orc_index_set_pq_table_f16.argtypes = [vp, i32]
         L.orc_pq_search_batch.restype = i32
@@ -295,13 +297,14 @@ def tie_swap_report(a_ids, a_d, b_ids, b_d, k=10, rel=1e-5):
             "unexplained": int(differing - explained), "rel_tolerance": rel, "largest_tie_gap_rel": float(worst)}
 
 
-def pq_create(rows, dim, m, ksub, seed=0, threads=8):
-    """codes [n, m] u8 and codebook [m, ksub, dim/m] (orc_pq_create)"""
+def pq_create(rows, dim, m, ksub, seed=0, threads=8, kmeans_iters=0, sample=0):
+    """codes [n, m] u8 and codebook [m, ksub, dim/m] (orc_pq_create_kmeans; kmeans_iters=0: random centroids)"""
     rows = np.ascontiguousarray(rows, dtype=np.float32)
     n, ld = rows.shape
     codes = np.zeros((n, m), dtype=np.uint8)
     codebook = np.zeros((m, ksub, dim // m), dtype=np.float32)
-    rc = lib().orc_pq_create(_p(rows), n, dim, ld, m, ksub, seed, _p(codes), _p(codebook), threads)
+    rc = lib().orc_pq_create_kmeans(_p(rows), n, dim, ld, m, ksub, seed, kmeans_iters, sample, _p(codes), _p(codebook),
+                                    threads)
     if rc:
         raise RuntimeError("orc_pq_create rc=%d" % rc)
     return codes, codebook

@@ -220,6 +220,9 @@ void orc_synth_clustered_rows(float *rows, uint64_t first, uint64_t count, uint3
 /* ---- product quantisation (pq.rs; per-sub-space codebooks, u8 codes: BASELINE config 5) ---- */
 /* random_centroids (pq.rs:261-285) per sub-space + Quantizer::quantize (pq.rs:61-71, exact
  * nearest centroid) for every row; codes [n][m], codebook [m][ksub][dim/m] */
+int orc_pq_create_kmeans(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub,
+                         uint64_t seed, uint32_t kmeans_iters, uint64_t sample, uint8_t *codes, float *codebook,
+                         int threads);
 int orc_pq_create(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub,
                   uint64_t seed, uint8_t *codes, float *codebook, int threads);
 void orc_pq_encode(const float *rows, uint64_t n, uint32_t ld, uint32_t m, uint32_t ksub, uint32_t dsub,

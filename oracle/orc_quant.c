@@ -197,20 +197,61 @@ void orc_pq_encode(const float *rows, uint64_t n, uint32_t ld, uint32_t m, uint3
   }
 }
 
-int orc_pq_create(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub, uint64_t seed,
-                  uint8_t *codes, float *codebook, int threads) {
+/* Codebooks.  kmeans_iters == 0: random_centroids (pq.rs:261-285), the sub-vectors of ksub randomly
+ * selected vectors.  kmeans_iters > 0 (per-sub-space k-means, own implementation;
+ * the reference's linfa k-means is dead code, pq.rs:215-259): Lloyd iterations from that start over
+ * the first min(n, sample) vectors of the same shuffle -- assign = the quantizer's exact nearest
+ * centroid, update = mean of the members accumulated in f64 IN TRAINING ORDER and rounded to f32 once
+ * (an empty cell keeps its centroid).  Every step is a fixed sequence of IEEE operations, so the
+ * device path (csrc/pq.hip) reproduces the codebook bit for bit. */
+int orc_pq_create_kmeans(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub,
+                         uint64_t seed, uint32_t kmeans_iters, uint64_t sample, uint8_t *codes, float *codebook,
+                         int threads) {
   if (m == 0 || dim % m || ksub == 0 || ksub > 256 || ksub > n) return -3;
   uint32_t dsub = dim / m;
-  /* random_centroids  pq.rs:261-285: sub-vectors of ksub randomly selected vectors */
   uint64_t *perm = (uint64_t *)malloc(sizeof(uint64_t) * n);
   for (uint64_t i = 0; i < n; i++) perm[i] = i;
   orc_shuffle_u64(perm, n, seed ^ 0x9C0DEB00C5ULL);
   for (uint32_t j = 0; j < m; j++)
     for (uint32_t k = 0; k < ksub; k++)
       memcpy(codebook + ((uint64_t)j * ksub + k) * dsub, rows + perm[k] * (uint64_t)ld + j * dsub, sizeof(float) * dsub);
+  if (kmeans_iters) {
+    uint64_t S = sample && sample < n ? sample : n;
+    if (S < ksub) S = ksub;
+    float *train = (float *)malloc(sizeof(float) * S * ld);
+    for (uint64_t i = 0; i < S; i++) memcpy(train + i * ld, rows + perm[i] * (uint64_t)ld, sizeof(float) * ld);
+    uint8_t *tc = (uint8_t *)malloc(S * m);
+    double *sum = (double *)malloc(sizeof(double) * (size_t)ksub * dsub);
+    uint64_t *cnt = (uint64_t *)malloc(sizeof(uint64_t) * ksub);
+    for (uint32_t it = 0; it < kmeans_iters; it++) {
+      orc_pq_encode(train, S, ld, m, ksub, dsub, codebook, tc, threads);
+      for (uint32_t j = 0; j < m; j++) {
+        memset(sum, 0, sizeof(double) * (size_t)ksub * dsub);
+        memset(cnt, 0, sizeof(uint64_t) * ksub);
+        for (uint64_t i = 0; i < S; i++) { /* every cell sees its members in training order */
+          uint32_t k = tc[i * m + j];
+          cnt[k]++;
+          for (uint32_t e = 0; e < dsub; e++) sum[(size_t)k * dsub + e] += (double)train[i * ld + j * dsub + e];
+        }
+        for (uint32_t k = 0; k < ksub; k++)
+          if (cnt[k])
+            for (uint32_t e = 0; e < dsub; e++)
+              codebook[((uint64_t)j * ksub + k) * dsub + e] = (float)(sum[(size_t)k * dsub + e] / (double)cnt[k]);
+      }
+    }
+    free(cnt);
+    free(sum);
+    free(tc);
+    free(train);
+  }
   free(perm);
   orc_pq_encode(rows, n, ld, m, ksub, dsub, codebook, codes, threads);
   return 0;
+}
+
+int orc_pq_create(const float *rows, uint64_t n, uint32_t dim, uint32_t ld, uint32_t m, uint32_t ksub, uint64_t seed,
+                  uint8_t *codes, float *codebook, int threads) {
+  return orc_pq_create_kmeans(rows, n, dim, ld, m, ksub, seed, 0, 0, codes, codebook, threads);
 }
 
 typedef struct {

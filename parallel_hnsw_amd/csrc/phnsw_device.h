@@ -76,6 +76,42 @@ __device__ __forceinline__ float chain_partial(const float4 (&x)[NV], const floa
   return a;
 }
 
+// The same chain for TWO queries against one row, as packed f32 operations (v_pk_fma_f32: two
+// independent IEEE fmas per instruction, so each half carries exactly the bits of chain_partial;
+// the plain v_fma_f32 issues at half the chip's f32 vector rate).  q2[k][e] = component e of chunk k
+// of (query a, query b).  Used by the dense top-layer tile pass (tiny.hip).
+typedef float ph_f2 __attribute__((ext_vector_type(2)));
+// NP pairs at once, the independent chains interleaved (k, e outer; pair inner) so that consecutive
+// instructions never depend on each other; every chain still sees its own operations in chain_partial's order
+template <int NV, int NP, bool EXACT, bool L2>
+__device__ __forceinline__ void chain_partial2(const float4 (&x)[NV], const ph_f2 (&q2)[NP][NV][4], uint32_t nv4,
+                                               uint32_t lane, ph_f2 (&a)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; j++) a[j] = ph_f2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    ph_f2 t[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) t[j] = a[j];
+    const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const ph_f2 xb = {xs[e], xs[e]};
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        if (L2) {
+          const ph_f2 d = q2[j][k][e] - xb;
+          t[j] = __builtin_elementwise_fma(d, d, t[j]);
+        } else {
+          t[j] = __builtin_elementwise_fma(q2[j][k][e], xb, t[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; j++) a[j] = (EXACT || lane + 64u * k < nv4) ? t[j] : a[j];
+  }
+}
+
 template <int NV, int U, bool EXACT, bool L2>
 __device__ __forceinline__ void rows_partial_impl(const float4 *const (&row)[U], const float4 (&q)[NV], uint32_t nv4,
                                                   uint32_t lane, float (&acc)[U]) {
@@ -193,6 +229,7 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
 template <int NV>
 struct DistF32 {
   static constexpr bool GLOBAL_TABLE = false;
+  static constexpr bool EARLY = false;
   float4 qv[NV];
   __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *, uint32_t lane) {
 #pragma unroll
@@ -270,6 +307,7 @@ struct DistPQT {
   // uses this one: the lookups become 2- or 4-byte gathers from L2, and the CU holds as many
   // searching waves as its registers allow instead of as many tables as its LDS allows
   static constexpr bool GLOBAL_TABLE = GLOBAL;
+  static constexpr bool EARLY = false;
   float *T;  // [m][ksub] (f32) or the same region viewed as uint16_t / uint8_t [m][ksub]
   float bias, scale;  // table mode 2 (8-bit entries): distance = bias + scale * sum of entries
   __device__ __forceinline__ float entry(const PhDistArgs &d, const float *qs, uint32_t j, uint32_t k, bool l2) const {
@@ -389,3 +427,64 @@ struct DistPQT {
 };
 typedef DistPQT<false> DistPQ;
 typedef DistPQT<true> DistPQG;
+
+// DistPQR<M>: the 8-bit lookup table (table mode 2) of a query held in REGISTERS -- the register file of a
+// CU (512 KiB) is larger than its LDS (160 KiB).  Row j of the table (256 one-byte entries) is exactly one
+// VGPR: lane l holds entries 4l .. 4l+3.  A candidate sits in one lane; its entry for sub-space j is
+// fetched from lane code_j >> 2 with ds_bpermute_b32 (the LDS crossbar, no LDS storage, no bank conflicts
+// between rows) and byte code_j & 3 is extracted.  The sum of the M entries is an exact integer, so the
+// distance bits equal DistPQT's mode 2 and the oracle's (ksub == 256 only).  The code rows of a hop's neighbours are requested
+// BEFORE the visited test-and-set returns (EARLY): the two round trips overlap; rows of already visited
+// neighbours are fetched for nothing (96 B each).
+template <int M>
+struct DistPQR {
+  // the table is built by DistPQT<true> in the wave's slot of global memory (the same code, hence the same
+  // bits, as table mode 2 everywhere else) and then read into registers once: row j = 256 bytes = one
+  // coalesced dword per lane
+  static constexpr bool GLOBAL_TABLE = true;
+  static constexpr bool EARLY = true;
+  uint32_t T[M];
+  uint32_t cw[M / 4];
+  float bias, scale;
+  __device__ __forceinline__ void load_table(DistPQT<true> &b, uint32_t lane) {
+    bias = b.bias;
+    scale = b.scale;
+    const uint32_t *t32 = (const uint32_t *)b.T;
+#pragma unroll
+    for (int j = 0; j < M; j++) T[j] = t32[j * 64 + lane];
+  }
+  __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *slot, uint32_t lane) {
+    DistPQT<true> b;
+    b.prepare_raw(d, q, slot, lane);
+    load_table(b, lane);
+  }
+  __device__ __forceinline__ void prepare_stored(const PhDistArgs &d, uint32_t vid, float *slot, uint32_t lane) {
+    DistPQT<true> b;
+    b.prepare_stored(d, vid, slot, lane);
+    load_table(b, lane);
+  }
+  // request the code row of the candidate in this lane (valid lanes only)
+  __device__ __forceinline__ void prefetch(const PhDistArgs &d, bool valid, uint32_t vid, uint32_t) {
+    const uint32_t *row = (const uint32_t *)(d.codes + (uint64_t)(valid ? vid : 0u) * M);
+#pragma unroll
+    for (int w = 0; w < M / 4; w++) cw[w] = row[w];
+  }
+  __device__ __forceinline__ float finish(const PhDistArgs &d, uint64_t mask, uint32_t lane) const {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+      const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c & 0xFCu), (int)T[j]);
+      sum += (t >> ((c & 3u) * 8u)) & 0xFFu;
+      // eight lookups in flight are enough to cover the crossbar's latency; without the fence the
+      // scheduler hoists all M of them and spills the table
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    float r = __fadd_rn(bias, __fmul_rn(scale, (float)sum));  // exact integer sum, two roundings
+    return ((mask >> lane) & 1ull) ? finalize_metric(r, d.metric) : 0.f;
+  }
+  __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) {
+    prefetch(d, (mask >> lane) & 1ull, vid, lane);
+    return finish(d, mask, lane);
+  }
+};

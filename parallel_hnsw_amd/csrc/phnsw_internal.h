@@ -243,7 +243,7 @@ void ph_workspace_order_free(PhWorkspace &ws);                                  
 #define PH_TWO_LAUNCH_MIN 32768u  // batches at least this large descend in two launches
 int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uint32_t ovf_cap);
 void ph_workspace_free(PhWorkspace &ws);
-uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds);
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds, int pqr_m = 0);
 static inline PhDistArgs ph_dist_args(const phnsw_store *s) {
   PhDistArgs d;
   d.vecs = s->rows;

@@ -39,9 +39,11 @@ __global__ void ph_pq_gather_codebook_kernel(const float *rows, uint32_t ld, con
 
 // one wave per vector; per sub-space every lane scores ksub/64 centroids with a sequential
 // fma chain over the dsub components, then the wave takes the minimum of (distance, k)
+// (codes[i * si + j * sj]: si = m, sj = 1 is the store's row layout; the k-means trainer uses the
+// transposed one, si = 1, sj = n)
 __global__ __launch_bounds__(64) void ph_pq_encode_kernel(const float *rows, uint32_t ld, uint64_t n, uint32_t m,
                                                           uint32_t ksub, uint32_t dsub, const float *codebook,
-                                                          uint8_t *codes) {
+                                                          uint8_t *codes, uint64_t si, uint64_t sj) {
   const uint32_t lane = threadIdx.x;
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
     const float *x = rows + i * ld;
@@ -63,9 +65,50 @@ __global__ __launch_bounds__(64) void ph_pq_encode_kernel(const float *rows, uin
         uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(best >> 32), s) << 32) | __shfl_xor((uint32_t)best, s);
         best = o < best ? o : best;
       }
-      if (lane == 0) codes[i * m + j] = (uint8_t)(best & 0xFF);
+      if (lane == 0) codes[i * si + j * sj] = (uint8_t)(best & 0xFF);
     }
   }
+}
+
+// k-means update of one cell (sub-space j, centroid k) per wave: the members' sub-vectors summed in f64
+// in training order (the ballot's set bits, ascending), mean rounded to f32 once; an empty cell keeps its
+// centroid.  tcT = training codes, transposed [m][S].  Definition shared with oracle/orc_quant.c.
+__global__ __launch_bounds__(64) void ph_pq_kmeans_update_kernel(const float *train, uint32_t ld, uint32_t S, uint32_t m,
+                                                                 uint32_t ksub, uint32_t dsub, const uint8_t *tcT,
+                                                                 float *codebook) {
+  const uint32_t lane = threadIdx.x, j = blockIdx.x / ksub, k = blockIdx.x % ksub;
+  double sum[4] = {0.0, 0.0, 0.0, 0.0};  // components lane, lane + 64, ... (dsub <= 256)
+  uint32_t cnt = 0;
+  for (uint32_t base = 0; base < S; base += 64) {
+    const uint32_t i = base + lane;
+    const bool mine = i < S && tcT[(uint64_t)j * S + i] == (uint8_t)k;
+    uint64_t mm = __ballot(mine);
+    cnt += __popcll(mm);
+    while (mm) {
+      const uint32_t b = __builtin_ctzll(mm);
+      mm &= mm - 1;
+      const float *x = train + (uint64_t)(base + b) * ld + (uint64_t)j * dsub;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t e = lane + 64u * c;
+        if (e < dsub) sum[c] += (double)x[e];
+      }
+    }
+  }
+  if (cnt) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t e = lane + 64u * c;
+      if (e < dsub) codebook[((uint64_t)j * ksub + k) * dsub + e] = (float)(sum[c] / (double)cnt);
+    }
+  }
+}
+
+__global__ void ph_pq_gather_train_kernel(const float *rows, uint32_t ld, const uint32_t *ids, uint32_t S, float *out) {
+  const uint32_t r = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (r >= S) return;
+  const float *src = rows + (uint64_t)ids[r] * ld;
+  for (uint32_t c = lane; c < ld; c += 64) out[(uint64_t)r * ld + c] = src[c];
 }
 
 __global__ void ph_pq_reconstruct_kernel(const uint8_t *codes, uint64_t n, uint32_t m, uint32_t ksub, uint32_t dsub,
@@ -127,7 +170,11 @@ __global__ __launch_bounds__(64) void ph_pq_rerank_kernel(PhDistArgs full, const
     if (rc__) return rc__; \
   } while (0)
 
-extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) try {
+// Codebooks: random_centroids (pq.rs:261-285) when kmeans_iters == 0, else Lloyd iterations from that
+// start over the first min(n, sample) vectors of the same shuffle (per-sub-space
+// k-means, own implementation -- the reference's linfa k-means is dead code, pq.rs:215-259).
+extern "C" int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
+                                            uint32_t kmeans_iters, uint64_t sample, phnsw_store **out) try {
   if (!full || !out || full->codes || !full->rows || m == 0 || ksub == 0 || ksub > 256 || (m % 4) ||
       (full->dim % m) || ksub > full->n) {
     ph_set_error("phnsw_store_create_pq: need an f32 store, m %% 4 == 0, dim %% m == 0, 1 <= ksub <= min(256, n)");
@@ -136,6 +183,10 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   if ((size_t)m * ksub * 4 > 150 * 1024) {
     ph_set_error("phnsw_store_create_pq: table m*ksub*4 = %zu bytes does not fit the 160 KiB LDS of a CU",
                  (size_t)m * ksub * 4);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  if (kmeans_iters && full->dim / m > 256) {
+    ph_set_error("phnsw_store_create_pq_kmeans: sub-vectors of more than 256 floats are not supported");
     return PHNSW_E_UNSUPPORTED;
   }
   PH_HIP(hipSetDevice(full->device));
@@ -150,34 +201,59 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   s->pq_m = m;
   s->pq_ksub = ksub;
   s->pq_dsub = dsub;
+  uint64_t S = kmeans_iters ? ((sample && sample < s->n) ? sample : s->n) : ksub;
+  if (S < ksub) S = ksub;
   uint32_t *sample_d = nullptr;
+  float *train = nullptr;
+  uint8_t *tcT = nullptr;
   int rc = 0;
   hipError_t e = hipMalloc(&s->codes, (size_t)s->n * m);
   if (e == hipSuccess) e = hipMalloc(&s->codebook, (size_t)m * ksub * dsub * 4);
-  if (e == hipSuccess) e = hipMalloc(&sample_d, (size_t)ksub * 4);
+  if (e == hipSuccess) e = hipMalloc(&sample_d, (size_t)S * 4);
   if (e != hipSuccess) rc = ph_hip_fail(e, "pq alloc", __FILE__, __LINE__);
   if (!rc) {
-    // random_centroids (pq.rs:261-285): the sub-vectors of ksub randomly selected vectors
     std::vector<uint64_t> perm(s->n);
     for (uint64_t i = 0; i < s->n; i++) perm[i] = i;
     ph_shuffle_u64(perm.data(), s->n, seed ^ 0x9C0DEB00C5ULL);
-    std::vector<uint32_t> sample(ksub);
-    for (uint32_t k = 0; k < ksub; k++) sample[k] = (uint32_t)perm[k];
-    e = hipMemcpy(sample_d, sample.data(), (size_t)ksub * 4, hipMemcpyHostToDevice);
+    std::vector<uint32_t> smp(S);
+    for (uint64_t k = 0; k < S; k++) smp[k] = (uint32_t)perm[k];
+    e = hipMemcpy(sample_d, smp.data(), (size_t)S * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = ph_hip_fail(e, "pq sample upload", __FILE__, __LINE__);
   }
   if (!rc) {
     uint32_t total = m * ksub * dsub;
     hipLaunchKernelGGL(ph_pq_gather_codebook_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, full->rows, full->ld,
                        sample_d, m, ksub, dsub, s->codebook);
+    e = hipGetLastError();
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq codebook", __FILE__, __LINE__);
+  }
+  if (!rc && kmeans_iters) {
+    e = hipMalloc(&train, (size_t)S * full->ld * 4);
+    if (e == hipSuccess) e = hipMalloc(&tcT, (size_t)S * m);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ph_pq_gather_train_kernel, dim3((uint32_t)((S + 3) / 4)), dim3(256), 0, 0, full->rows, full->ld,
+                         sample_d, (uint32_t)S, train);
+      for (uint32_t it = 0; it < kmeans_iters; it++) {
+        hipLaunchKernelGGL(ph_pq_encode_kernel, dim3((uint32_t)std::min<uint64_t>(S, 256u * 32u)), dim3(64), 0, 0, train,
+                           full->ld, S, m, ksub, dsub, s->codebook, tcT, (uint64_t)1, S);
+        hipLaunchKernelGGL(ph_pq_kmeans_update_kernel, dim3(m * ksub), dim3(64), 0, 0, train, full->ld, (uint32_t)S, m, ksub,
+                           dsub, tcT, s->codebook);
+      }
+      e = hipGetLastError();
+    }
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq k-means", __FILE__, __LINE__);
+  }
+  if (!rc) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(s->n, 256u * 32u);
     hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, full->rows, full->ld, s->n, m, ksub, dsub,
-                       s->codebook, s->codes);
+                       s->codebook, s->codes, (uint64_t)m, (uint64_t)1);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) rc = ph_hip_fail(e, "pq encode", __FILE__, __LINE__);
   }
   if (sample_d) hipFree(sample_d);
+  if (train) hipFree(train);
+  if (tcT) hipFree(tcT);
   if (rc) {
     if (s->codes) hipFree(s->codes);
     if (s->codebook) hipFree(s->codebook);
@@ -186,6 +262,10 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   }
   *out = s;
   return 0;
+} catch (...) { return ph_caught(); }
+
+extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) try {
+  return phnsw_store_create_pq_kmeans(full, m, ksub, seed, 0, 0, out);
 } catch (...) { return ph_caught(); }
 
 // How the per-query lookup table T[m][ksub] is stored.  0: f32, the
@@ -226,7 +306,7 @@ extern "C" int phnsw_pq_quantize(const phnsw_store *s, const float *rows, uint64
   if (e == hipSuccess) {
     uint32_t grid = (uint32_t)std::min<uint64_t>(n, 256u * 32u);
     hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, rd, dim, n, s->pq_m, s->pq_ksub, s->pq_dsub,
-                       s->codebook, cd);
+                       s->codebook, cd, (uint64_t)s->pq_m, (uint64_t)1);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(out_codes, cd, (size_t)n * s->pq_m, hipMemcpyDeviceToHost);
@@ -322,7 +402,8 @@ extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *f
     if (e == hipSuccess) e = hipMemset(qq, 0, (size_t)nq * full->ld * 4);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(ph_pq_encode_kernel, dim3((uint32_t)std::min<uint64_t>(nq, 8192)), dim3(64), 0, 0, qd,
-                         full->ld, nq, ps->pq_m, ps->pq_ksub, ps->pq_dsub, ps->codebook, qcodes);
+                         full->ld, nq, ps->pq_m, ps->pq_ksub, ps->pq_dsub, ps->codebook, qcodes, (uint64_t)ps->pq_m,
+                         (uint64_t)1);
       uint64_t tot = nq * full->dim;
       hipLaunchKernelGGL(ph_pq_reconstruct_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, 0, qcodes, nq,
                          ps->pq_m, ps->pq_ksub, ps->pq_dsub, ps->codebook, qq, full->ld);

@@ -38,7 +38,7 @@
 #include "phnsw_device.h"
 
 template <int CAPC, class Dist>
-__global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
+__device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   extern __shared__ uint32_t smem[];
   constexpr int CAP = CAPC * 64;
   uint32_t *Cid = smem;                    // running candidates: VectorIds (search.rs:110)
@@ -237,12 +237,15 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
       // ---- closest_nodes  lib.rs:175-248
       uint32_t ovf_n = 0;
       uint32_t pd = a.probe_depth;
+      // every queue entry below scan_from has been expanded: the pop scan starts at its 64-entry chunk,
+      // and a hop's merge touches only the chunks from its first insertion point on
+      uint32_t scan_from = 0;
       for (;;) {
         // visit_queue.pop(): smallest (d,id) among not yet expanded nodes  lib.rs:191,243-244
         int pop = -1;
 #pragma unroll
         for (int c = 0; c < CAPC; c++) {
-          if (pop < 0) {
+          if (pop < 0 && 64u * (c + 1) > scan_from) {
             uint32_t i = lane + 64u * c;
             bool f = i < qlen && !(Qid[i] & EXPF);
             uint64_t b = __ballot(f);
@@ -289,6 +292,13 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         // get_neighbors(next) + filter(!visited)  lib.rs:195-198
         uint32_t nb = PH_EMPTY32;
         if (lane < L.W) nb = L.neighbors[(uint64_t)cur * L.W + lane];
+        if constexpr (Dist::EARLY) {
+          // the candidates' rows are requested before the visited test-and-set below returns
+          const bool valid = nb < L.n_nodes;
+          uint32_t v = 0;
+          if (valid) v = identity ? nb : L.nodes[nb];
+          dist.prefetch(a.dist, valid, v, lane);
+        }
         bool fresh = false;
         if (nb < L.n_nodes) {
           uint32_t bit = 1u << (nb & 31);
@@ -305,6 +315,8 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         if (tl) {
           myd = 0.f;
           if (fresh) myd = tiny_lds_row ? Dl[nb] : Dg[nb];
+        } else if constexpr (Dist::EARLY) {
+          myd = dist.finish(a.dist, fm, lane);
         } else {
           uint32_t vid = 0;
           if (fresh) vid = identity ? nb : L.nodes[nb];
@@ -315,72 +327,77 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
         // (visited), so final slot = (#queue keys below) + (#batch keys below).
         const uint64_t key = fresh ? mkkey(myd, nb) : KEY_NONE;
-        uint32_t qi[CAPC];
-        float qd[CAPC];
-        uint64_t qk[CAPC];
-        uint32_t sh[CAPC];
-#pragma unroll
-        for (int c = 0; c < CAPC; c++) {
-          uint32_t i = lane + 64u * c;
-          sh[c] = 0;
-          if (i < qlen) {
-            qi[c] = Qid[i];
-            qd[c] = Qd[i];
-            qk[c] = mkkey(qd[c], qi[c]);
-          } else {
-            qi[c] = PH_EMPTY32;
-            qd[c] = PH_FMAX;
-            qk[c] = KEY_NONE;
-          }
-        }
-        uint32_t rank = 0;
-        {
-          uint64_t rem = fm;
-          while (rem) {
-            int j = __builtin_ctzll(rem);
-            rem &= rem - 1;
-            uint64_t kj = rl64(key, j);
-            rank += (kj < key) ? 1u : 0u;
-#pragma unroll
-            for (int c = 0; c < CAPC; c++) sh[c] += (kj < qk[c]) ? 1u : 0u;
-          }
-        }
-        uint32_t pos = 0;
-        if (fresh) pos = lds_lower_bound(Qid, Qd, qlen, key);
-        const uint32_t newpos = pos + rank;
-
+        // An element that is worse than the tail of a FULL queue cannot enter it: it goes straight to
+        // the spill list and takes no part in the merge.  Late in a layer most hops bring nothing
+        // else; those skip the merge altogether.
+        const bool full = qlen == ef;
+        const float dtail = full ? Qd[ef - 1] : PH_FMAX;
+        const uint64_t tailkey = full ? mkkey(dtail, Qid[ef - 1]) : KEY_NONE;
+        const bool ins = fresh && key < tailkey;
+        const uint64_t im = __ballot(ins);
+        uint32_t pos = 0, pos_min = 0xFFFFFFFFu, newpos = 0xFFFFFFFFu;
         // merge()'s return value (priority_queue.rs:109-144), closed form for a sorted,
         // duplicate-free batch e_0 < e_1 < ...: the first element decides.  It is inserted
         // (true) unless it ranks past a full queue; then Err(i>=cap) => break => false,
         // except when its priority ties the queue's tail (Ok branch returns cap, false) and
         // a second element follows (Err(0) on the empty slice => true without writing).
-        bool did = false;
-        if (m > 0) {
-          uint64_t e0 = __ballot(fresh && rank == 0);
-          int le = __builtin_ctzll(e0);
-          uint32_t pos0 = rl32(pos, le);
-          float d0 = __uint_as_float(rl32(__float_as_uint(myd), le));
-          did = pos0 < ef || (qlen == ef && Qd[ef - 1] == d0 && m >= 2);
-        }
-        __syncthreads();  // every lane has its queue slice in registers
-
-        // move everything to its final slot; what falls past `ef` is spilled
+        // e_0 enters the queue exactly when some element does (im != 0); otherwise every distance is
+        // >= the tail's, so e_0 ties the tail exactly when some element's distance equals it.
+        bool did = im != 0;
+        if (!im && m >= 2) did = __ballot(fresh && myd == dtail) != 0;
+        if (im) {
+          if (ins) pos = lds_lower_bound(Qid, Qd, qlen, key);
+          // queue entries below the smallest insertion point stay where they are: their chunks are
+          // neither read nor rewritten
+          pos_min = ins ? pos : 0xFFFFFFFFu;
 #pragma unroll
-        for (int c = 0; c < CAPC; c++) {
-          uint32_t i = lane + 64u * c;
-          bool has = i < qlen;
-          uint32_t np = i + sh[c];
-          if (has && np < ef) {
-            Qid[np] = qi[c];
-            Qd[np] = qd[c];
+          for (int sft = 32; sft >= 1; sft >>= 1) pos_min = min(pos_min, (uint32_t)__shfl_xor(pos_min, sft));
+          const uint32_t c_first = pos_min >> 6;
+          // rank of each entering element among the entering elements
+          uint32_t rank = 0;
+          {
+            uint64_t rem = im;
+            while (rem) {
+              int j = __builtin_ctzll(rem);
+              rem &= rem - 1;
+              rank += (rl64(key, j) < key) ? 1u : 0u;
+            }
           }
-          bool spill = has && np >= ef;
-          uint64_t sm = __ballot(spill);
-          if (sm) {
-            uint32_t at = ovf_n + __popcll(sm & lt);
-            if (spill && at < a.ovf_cap) ovf[at] = make_uint2(qi[c], __float_as_uint(qd[c]));
-            ovf_n += __popcll(sm);
+          if (ins) newpos = pos + rank;
+          // Shift the queue in place, TOP chunk first: an entry moves up by the number of entering keys
+          // below it, i.e. into its own chunk or the one above -- both already read.  One chunk of the
+          // queue is in registers at a time (a wave's LDS reads and writes execute in program order).
+          // What falls past `ef` is spilled.
+#pragma unroll
+          for (int c = CAPC - 1; c >= 0; c--) {
+            if ((uint32_t)c < c_first || 64u * c >= qlen) continue;
+            const uint32_t i = lane + 64u * c;
+            const bool has = i < qlen;
+            const uint32_t qi = has ? Qid[i] : PH_EMPTY32;
+            const float qd = has ? Qd[i] : PH_FMAX;
+            const uint64_t qk = has ? mkkey(qd, qi) : KEY_NONE;
+            uint32_t sh = 0;
+            uint64_t rem = im;
+            while (rem) {
+              int j = __builtin_ctzll(rem);
+              rem &= rem - 1;
+              sh += (rl64(key, j) < qk) ? 1u : 0u;
+            }
+            const uint32_t np = i + sh;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the chunk is in registers before it is overwritten
+            if (has && np < ef) {
+              Qid[np] = qi;
+              Qd[np] = qd;
+            }
+            const bool spill = has && np >= ef;
+            const uint64_t sm = __ballot(spill);
+            if (sm) {
+              uint32_t at = ovf_n + __popcll(sm & lt);
+              if (spill && at < a.ovf_cap) ovf[at] = make_uint2(qi, __float_as_uint(qd));
+              ovf_n += __popcll(sm);
+            }
           }
+          __syncthreads();
         }
         {
           if (fresh && newpos < ef) {
@@ -396,6 +413,7 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
           }
         }
         qlen = min(ef, qlen + m);
+        scan_from = min(pop >= 0 ? (uint32_t)pop + 1u : scan_from, pos_min);
         __syncthreads();
         if (ovf_n > a.ovf_cap) {
           err = ST_OVERFLOW;
@@ -590,12 +608,39 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   }
 }
 
+template <int CAPC, class Dist>
+__global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
+  ph_search_body<CAPC, Dist>(a);
+}
+
+// the register-table policy keeps a whole lookup table in VGPRs: two waves per SIMD is its register budget
+template <int CAPC, int M>
+__global__ __launch_bounds__(64, 2) void ph_search_kernel_pqr(PhSearchArgs a) {
+  ph_search_body<CAPC, DistPQR<M>>(a);
+}
+
 // ------------------------------------------------------------------ host side
 
 typedef void (*ph_search_fn)(PhSearchArgs);
 
 static int pick_capc(uint32_t ef) { return ef <= 128 ? 2 : (ef <= 512 ? 8 : (ef <= 1024 ? 16 : 0)); }
 static int pick_nv(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
+
+// the register-table policy serves 8-bit tables (mode 2) of exactly 32 / 64 / 96 / 128 sub-spaces with at most
+// 256 centroids and queues of up to 512 entries; PHNSW_PQ_TABLE=lds|global selects the older table placements
+static int pick_pqr(const phnsw_store *s, int capc) {
+  if (!s->codes || s->pq_table_f16 != 2 || (capc != 2 && capc != 8) || getenv("PHNSW_PQ_TABLE")) return 0;
+  const uint32_t m = s->pq_m;
+  return (s->pq_ksub == 256 && (m == 32 || m == 64 || m == 96 || m == 128)) ? (int)m : 0;
+}
+static ph_search_fn pick_kernel_pqr(int capc, int m) {
+#define PH_KR(C, M) \
+  if (capc == C && m == M) return (ph_search_fn)ph_search_kernel_pqr<C, M>;
+  PH_KR(2, 32) PH_KR(2, 64) PH_KR(2, 96) PH_KR(2, 128)
+  PH_KR(8, 32) PH_KR(8, 64) PH_KR(8, 96) PH_KR(8, 128)
+#undef PH_KR
+  return nullptr;
+}
 
 // nv == 0 selects the product-quantised policy
 static ph_search_fn pick_kernel(int capc, int nv) {
@@ -616,10 +661,10 @@ static ph_search_fn pick_kernel(int capc, int nv) {
 // pq_lds: bytes behind the queues -- the PQ lookup table, or the dense-top-layer table row + visited bits
 static size_t lds_bytes(int capc, size_t pq_lds) { return (size_t)(5 * capc * 64 + 64) * 4 + pq_lds; }
 
-uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds) {
+uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds, int pqr_m) {
   int capc = pick_capc(ef), nv = pq ? 0 : pick_nv(nv4);
   if (!capc || (!pq && !nv)) return 0;
-  ph_search_fn fn = pick_kernel(capc, nv);
+  ph_search_fn fn = pqr_m ? pick_kernel_pqr(capc, pqr_m) : pick_kernel(capc, nv);
   if (!fn) return 0;
   int dev = 0;
   hipGetDevice(&dev);
@@ -661,9 +706,10 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   uint64_t max_nodes = 0;
   for (auto &l : ix->layers) max_nodes = std::max<uint64_t>(max_nodes, l.n_nodes);
   uint64_t words = (max_nodes + 31) / 32 + 1;
-  const bool pqg = ix->store->codes != nullptr && ph_pq_global_tables();
+  const int pqr = pick_pqr(ix->store, pick_capc(ef));
+  const bool pqg = ix->store->codes != nullptr && (ph_pq_global_tables() || pqr);  // (the register policy stages its table there)
   uint32_t slots = ph_search_slots(ef, ix->store->ld / 4, ix->store->codes != nullptr,
-                                   pqg ? 0 : ph_pq_lds_bytes(ix->store));
+                                   pqg ? 0 : ph_pq_lds_bytes(ix->store), pqr);
   if (slots == 0) {
     ph_set_error("unsupported search shape: ef=%u dim=%u (ef <= 1024, dim <= 1536; PQ table + queue <= 160 KB LDS)", ef,
                  ix->store->dim);
@@ -718,11 +764,12 @@ int ph_search_begin(PhWorkspace &ws, hipStream_t stream) {
 
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end) {
   const bool pq = ix->store->codes != nullptr;
-  const size_t pq_lds = pq ? (ph_pq_global_tables() ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
+  int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
+  const int pqr = pick_pqr(ix->store, capc);
+  const size_t pq_lds = pq ? ((pqr || ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
   a.pq_tables = ws.pq_tables;
   a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
-  int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
-  ph_search_fn fn = (capc && (pq || nv)) ? pick_kernel(capc, nv) : nullptr;
+  ph_search_fn fn = (capc && (pq || nv)) ? (pqr ? pick_kernel_pqr(capc, pqr) : pick_kernel(capc, nv)) : nullptr;
   if (!fn) {
     ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);
     return PHNSW_E_UNSUPPORTED;
@@ -732,7 +779,7 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   a.ovf = ws.ovf;
   a.ovf_cap = ws.ovf_cap;
   a.counter = ws.counter;
-  uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds), ws.n_slots);
+  uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds, pqr), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
   PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));

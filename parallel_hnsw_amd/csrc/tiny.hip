@@ -78,6 +78,7 @@ struct PhTinyTableArgs {
   uint32_t tiny_n, stride;
   float *D;
   uint32_t rows_per_slice;  // multiple of 8
+  uint32_t dbg;             // PHNSW_TINY_DBG (experiments): 1 = no table stores, 2 = stage only the first tile
 };
 
 // two registers folded into one: lanes whose bit `m` is clear keep A's butterfly step, the others
@@ -118,7 +119,7 @@ __device__ __forceinline__ float fold2(float A, float B, uint32_t lane) {
 }
 
 template <int NV, int QT, bool EXACT, bool L2>
-__device__ __forceinline__ void tiny_tile(const float4 *lds, const float4 (&qv)[QT][NV], uint32_t nv4, uint32_t lane,
+__device__ __forceinline__ void tiny_tile(const float4 *lds, const ph_f2 (&qv)[QT / 2][NV][4], uint32_t nv4, uint32_t lane,
                                           float &V) {
   float R[8];
 #pragma unroll
@@ -127,8 +128,13 @@ __device__ __forceinline__ void tiny_tile(const float4 *lds, const float4 (&qv)[
 #pragma unroll
     for (int k = 0; k < NV; k++) x[k] = lds[(i * NV + k) * 64 + lane];
     float p[QT];
+    ph_f2 pp[QT / 2];
+    chain_partial2<NV, QT / 2, EXACT, L2>(x, qv, nv4, lane, pp);
 #pragma unroll
-    for (int j = 0; j < QT; j++) p[j] = chain_partial<NV, EXACT, L2>(x, qv[j], nv4, lane);
+    for (int j = 0; j < QT / 2; j++) {
+      p[2 * j] = pp[j].x;
+      p[2 * j + 1] = pp[j].y;
+    }
     if constexpr (QT == 8) {
       float f0 = fold2<32>(p[0], p[1], lane), f1 = fold2<32>(p[2], p[3], lane);
       float f2 = fold2<32>(p[4], p[5], lane), f3 = fold2<32>(p[6], p[7], lane);
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) void ph_tiny_table_kernel(PhTinyTableArgs a) {
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint32_t nv4 = a.dist.nv4;
   const uint32_t p0 = (blockIdx.x * 4u + w) * QT;
-  float4 qv[QT][NV];
+  // queries in pairs: qv[j][k][e] = component e of chunk k of (query 2j, query 2j + 1)
+  ph_f2 qv[QT / 2][NV][4];
 #pragma unroll
   for (int j = 0; j < QT; j++) {
     const uint32_t p = p0 + j;
@@ -166,7 +173,11 @@ __global__ __launch_bounds__(256) void ph_tiny_table_kernel(PhTinyTableArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       const uint32_t c = lane + 64u * k;
-      qv[j][k] = (valid && c < nv4) ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = (valid && c < nv4) ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      qv[j / 2][k][0][j & 1] = v.x;
+      qv[j / 2][k][1][j & 1] = v.y;
+      qv[j / 2][k][2][j & 1] = v.z;
+      qv[j / 2][k][3][j & 1] = v.w;
     }
   }
   const bool exact = nv4 == 64u * NV, l2 = a.dist.metric == PHNSW_METRIC_L2;
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256) void ph_tiny_table_kernel(PhTinyTableArgs a) {
   const uint32_t r_end = min(a.tiny_n, r_begin + a.rows_per_slice);
   for (uint32_t r0 = r_begin; r0 < r_end; r0 += 8) {
     __syncthreads();  // the previous tile has been consumed
+    if (!(a.dbg & 2u) || r0 == r_begin)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const uint32_t slot = 2u * w + u;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void ph_tiny_table_kernel(PhTinyTableArgs a) {
       writer = (lane & 1u) == 0u;
     }
     const uint32_t p = p0 + j, r = r0 + i;
-    if (writer && p < a.npos && r < r_end) a.D[(uint64_t)p * a.stride + r] = finalize_metric(V, a.dist.metric);
+    if (writer && p < a.npos && r < r_end && !(a.dbg & 1u)) a.D[(uint64_t)p * a.stride + r] = finalize_metric(V, a.dist.metric);
   }
 }
 
@@ -307,6 +319,7 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
   t.tiny_n = tn;
   t.stride = stride;
   t.D = ws.tiny_d;
+  if (const char *e = getenv("PHNSW_TINY_DBG")) t.dbg = (uint32_t)atoi(e);
   const uint32_t nv4 = a.dist.nv4;
   const int nv = nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : 6);
   const uint32_t qt = nv == 6 ? 4u : 8u;

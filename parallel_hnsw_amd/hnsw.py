@@ -154,10 +154,11 @@ class PqStore(VectorStore):
 
     TABLE_MODES = {"f32": 0, "f16": 1, "u8": 2}
 
-    def __init__(self, full, m, ksub=256, seed=0, table_f16=False, table_mode=None):
-        """table_mode: "f32" (reference arithmetic), "f16" or "u8" (phnsw_pq_set_table_mode)"""
+    def __init__(self, full, m, ksub=256, seed=0, table_f16=False, table_mode=None, kmeans_iters=0, kmeans_sample=0):
+        """table_mode: "f32" (reference arithmetic), "f16" or "u8" (phnsw_pq_set_table_mode); kmeans_iters: Lloyd
+        iterations on the codebooks (0 = the reference's random_centroids, pq.rs:261-285)"""
         h = C.c_void_p()
-        check(lib().phnsw_store_create_pq(full._h, m, ksub, seed, C.byref(h)))
+        check(lib().phnsw_store_create_pq_kmeans(full._h, m, ksub, seed, kmeans_iters, kmeans_sample, C.byref(h)))
         VectorStore.__init__(self, _handle=h, device=full.device)
         mode = self.TABLE_MODES[table_mode] if table_mode is not None else int(table_f16)
         if mode:
@@ -207,7 +208,7 @@ class QuantizedHnsw:
     """QuantizedHnsw (pq.rs:120-131, 287-364): quantizer + Hnsw over the codes + full comparator"""
 
     def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False,
-                 table_mode=None):
+                 table_mode=None, kmeans_iters=0, kmeans_sample=0, graph=None):
         """QuantizedHnsw::new(number_of_centroids, comparator, bp): per-sub-space codebooks of
         `number_of_centroids` (<= 256) centroids, encode, Hnsw::generate over the codes.
 
@@ -218,9 +219,14 @@ class QuantizedHnsw:
         the candidates) never finishes at scale -- in the reference as much as here."""
         m = m or max(4, comparator.dim // 8)
         self.full = comparator
-        self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16, table_mode)
+        self.store = PqStore(comparator, m, number_of_centroids, seed, table_f16, table_mode, kmeans_iters, kmeans_sample)
         vids = np.arange(comparator.n, dtype=np.uint64) if vids is None else vids
-        self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters(promote=0))
+        if graph is not None:
+            # `graph`: an Hnsw built over the full-precision comparator; its layers are adopted over the code rows
+            # (phnsw_index_from_layers), so the traversal follows the full-precision graph with quantised distances
+            self.hnsw = Hnsw.from_layers(self.store, [(l.nodes, l.neighbors) for l in graph.layers], graph.build_parameters)
+        else:
+            self.hnsw = Hnsw.generate(self.store, vids, bp or BuildParameters(promote=0))
 
     def search_batch(self, queries, sp=None, quantize_query=False, stats=False):
         sp = sp or SearchParameters()

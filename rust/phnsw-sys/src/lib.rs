@@ -172,6 +172,8 @@ extern "C" {
     // ---- product quantisation (pq.rs)
     pub fn phnsw_store_create_pq(full: *mut phnsw_store, m: u32, ksub: u32, seed: u64,
                                  out: *mut *mut phnsw_store) -> c_int;
+    pub fn phnsw_store_create_pq_kmeans(full: *mut phnsw_store, m: u32, ksub: u32, seed: u64, kmeans_iters: u32,
+                                        sample: u64, out: *mut *mut phnsw_store) -> c_int;
     pub fn phnsw_pq_info(s: *const phnsw_store, m: *mut u32, ksub: *mut u32, dsub: *mut u32) -> c_int;
     pub fn phnsw_pq_set_table_mode(s: *mut phnsw_store, mode: c_int) -> c_int;
     pub fn phnsw_pq_set_table_f16(s: *mut phnsw_store, on: c_int) -> c_int;

@@ -3,6 +3,8 @@ codebooks, codes, the graph built over the code rows, quantised search and the
 full-precision re-rank, against the oracle's definition of the same flow (oracle/orc_quant.c).
 The reference pins no numeric value here ("parity unpinned"); what is checked is
 bit equality with the oracle and the recall the reference's tests assert."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,6 +20,25 @@ def make(n, dim, m, ksub, seed=0, metric=0, clustered=False, table_f16=False):
     pq = ph.PqStore(full, m, ksub, seed, table_f16=table_f16)
     ocodes, ocb = oracle.pq_create(rows, dim, m, ksub, seed)
     return rows, full, pq, ocodes, ocb
+
+
+@pytest.mark.parametrize("n,dim,m,ksub,iters,sample", [(3000, 64, 16, 64, 5, 0), (5000, 96, 12, 256, 3, 2000),
+                                                      (900, 32, 4, 16, 8, 500), (2000, 768, 96, 32, 2, 1000)])
+def test_kmeans_codebooks_equal_the_oracle(n, dim, m, ksub, iters, sample):
+    """per-sub-space k-means: f64 member sums in training order, exact nearest-centroid
+    assignment -- codebook and codes bit for bit the oracle's, and a lower reconstruction error than
+    random_centroids (pq.rs:261-285)"""
+    rows = oracle.synth_clustered_rows(0, n, dim, n_clusters=25)
+    full = ph.VectorStore(rows[:, :dim])
+    pq = ph.PqStore(full, m, ksub, seed=7, kmeans_iters=iters, kmeans_sample=sample)
+    ocodes, ocb = oracle.pq_create(rows, dim, m, ksub, seed=7, kmeans_iters=iters, sample=sample)
+    np.testing.assert_array_equal(pq.codebook().view(np.uint32), ocb.view(np.uint32))
+    np.testing.assert_array_equal(pq.codes(), ocodes)
+    rnd = ph.PqStore(full, m, ksub, seed=7)
+
+    def mse(st):
+        return float(((st.reconstruct(st.codes()) - rows[:, :dim]) ** 2).sum(1).mean())
+    assert mse(pq) < mse(rnd)
 
 
 @pytest.mark.parametrize("metric", [0, 2])
@@ -194,3 +215,48 @@ def test_quantize_and_reconstruct_arbitrary_vectors():
     want = np.concatenate([ocb[j, codes[:, j]] for j in range(m)], axis=1)
     np.testing.assert_array_equal(rec.view(np.uint32), want.view(np.uint32))
     np.testing.assert_array_equal(pq.quantize(rows[:50, :dim]), ocodes[:50])  # stored rows: their own codes
+
+
+@pytest.mark.parametrize("m,ef,pd", [(96, 64, 2), (96, 300, 4), (32, 128, 3), (64, 40, 2), (128, 100, 2)])
+def test_register_table_search_equals_the_other_table_placements_and_the_oracle(m, ef, pd):
+    """8-bit tables of 32 / 64 / 96 / 128 sub-spaces x 256 centroids are held in VGPRs and looked up with
+    ds_bpermute (DistPQR); LDS and global placements (PHNSW_PQ_TABLE) and the oracle must give the same bits"""
+    n, dim = 6000, 768 if m == 96 else 4 * m
+    rows = oracle.synth_clustered_rows(0, n, dim, n_clusters=30)
+    full = ph.VectorStore(rows[:, :dim])
+    qh = ph.QuantizedHnsw(256, full, ph.BuildParameters(promote=0, max_link_rounds=1, seed=2), m=m, kmeans_iters=2, kmeans_sample=3000)
+    qh.store.set_table_mode("u8")
+    q = oracle.synth_clustered_rows(2 ** 32, 200, dim, n_clusters=30)[:, :dim]
+    sp = ph.SearchParameters(ef, ef, pd)
+    reg = qh.hnsw.search_batch(queries=q, sp=sp, stats=True)
+    for placement in ("lds", "global"):
+        os.environ["PHNSW_PQ_TABLE"] = placement
+        try:
+            other = qh.hnsw.search_batch(queries=q, sp=sp, stats=True)
+        finally:
+            del os.environ["PHNSW_PQ_TABLE"]
+        for a, b in zip(reg, other):
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                          b.view(np.uint32) if b.dtype == np.float32 else b)
+    # Stored queries (their table is that of the reconstruction)
+    qid = np.arange(0, n, 11, dtype=np.uint64)
+    r2 = qh.hnsw.search_batch(qids=qid, sp=sp, exclude=qid, stats=True)
+    os.environ["PHNSW_PQ_TABLE"] = "global"
+    try:
+        o2 = qh.hnsw.search_batch(qids=qid, sp=sp, exclude=qid, stats=True)
+    finally:
+        del os.environ["PHNSW_PQ_TABLE"]
+    for a, b in zip(r2, o2):
+        np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                      b.view(np.uint32) if b.dtype == np.float32 else b)
+    # the oracle on the same codes / codebook / graph
+    ocodes, ocb = oracle.pq_create(rows, dim, m, 256, seed=0, kmeans_iters=2, sample=3000)
+    np.testing.assert_array_equal(qh.store.codes(), ocodes)
+    oix = oracle.Index(rows, dim=dim, metric=oracle.METRIC_COSINE_HALF, sum_mode=oracle.SUM_BLOCKED64)
+    for l in qh.hnsw.layers:
+        oix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    oix.set_pq(ocodes, ocb, table_f16=2)
+    ci, cd, cl, cs = oix.search(queries=q, sp=(ef, ef, pd), stats=True)
+    np.testing.assert_array_equal(reg[0], ci)
+    np.testing.assert_array_equal(reg[1].view(np.uint32), cd.view(np.uint32))
+    np.testing.assert_array_equal(reg[3], cs)
