@@ -269,6 +269,19 @@ int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t
  * min(n, sample) vectors of the seeded shuffle (sample 0 = all); kmeans_iters 0 == phnsw_store_create_pq */
 int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
                                  uint32_t kmeans_iters, uint64_t sample, phnsw_store **out);
+/* The reference's own quantizer shape (src/pq.rs:19-27, 61-81, 261-364): ONE codebook of n_centroids <= 65535
+ * centroid sub-vectors of dsub floats shared by every sub-space (random_centroids: the sub-vectors of selected
+ * vectors, sorted, de-duplicated, shuffled, truncated), u16 codes, quantize = the best result of an HNSW search
+ * (quantized_search) over the centroids (built with centroid_bp, centroid_metric).  A stored vector IS its
+ * reconstruction and distances apply the store's metric to reconstructions (the quantised comparators of
+ * pq.rs:585-599), so the store is searched with phnsw_search_batch* / phnsw_pq_search_batch like any other.
+ * Build the Hnsw over the quantised vectors on phnsw_pq_shared_reconstruct_store (same distance bits) and
+ * adopt it with phnsw_index_from_layers.  dim % dsub == 0, dsub % 4 == 0. */
+int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
+                                 const phnsw_build_params *centroid_bp, const phnsw_search_params *quantized_search,
+                                 int centroid_metric, phnsw_store **out);
+int phnsw_pq_shared_read(const phnsw_store *s, uint16_t *codes, float *codebook);
+int phnsw_pq_shared_reconstruct_store(const phnsw_store *s, phnsw_store **out);
 int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);
 /* storage of the per-query lookup table: 0 = f32 (reference arithmetic), 1 = IEEE half entries,
  * 2 = 8-bit entries with a per-query scale (integer sums; fewest L2 requests per hop).  Modes 1

@@ -92,6 +92,9 @@ SYMBOLS = {
                                  C.POINTER(_u64)]),
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),
     "phnsw_store_create_pq_kmeans": (_i32, [_vp, _u32, _u32, _u64, _u32, _u64, _pp]),
+    "phnsw_store_create_pq_shared": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(BuildParams), C.POINTER(SearchParams), _i32, _pp]),
+    "phnsw_pq_shared_read": (_i32, [_vp, _vp, _vp]),
+    "phnsw_pq_shared_reconstruct_store": (_i32, [_vp, _pp]),
     "phnsw_pq_info": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "phnsw_pq_quantize": (_i32, [_vp, _vp, _u64, _vp]),
     "phnsw_pq_reconstruct": (_i32, [_vp, _vp, _u64, _vp]),

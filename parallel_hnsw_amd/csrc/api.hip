@@ -315,6 +315,9 @@ extern "C" void phnsw_store_destroy(phnsw_store *s) {
   hipSetDevice(s->device);
   if (s->owns_rows && s->rows) hipFree(s->rows);
   if (s->codes) hipFree(s->codes);
+  if (s->codes16) hipFree(s->codes16);
+  if (s->centroid_index) phnsw_index_destroy(s->centroid_index);  // (releases its reference to centroid_store)
+  if (s->centroid_store) phnsw_store_destroy(s->centroid_store);
   if (s->codebook) hipFree(s->codebook);
   ph_store_anchors_free(s);
   delete s;

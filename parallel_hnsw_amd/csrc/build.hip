@@ -401,7 +401,8 @@ __global__ __launch_bounds__(64) void ph_row_dist_kernel(PhDistArgs da, const ui
 
 // top-M search results (VectorIds) of node i -> proposals "insert i into row of result k"
 // for (neighbor_vec, distance) in matches.take(M) { if neighbor_vec == vector { break } .. }  lib.rs:1118-1122
-__global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const uint32_t *vec2node,
+// (ids arrive from other ranks in the sharded build: anything outside the store is dropped, never dereferenced)
+__global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const uint32_t *vec2node, uint32_t n_store,
                                        const uint32_t *res_ids, const uint32_t *res_len, uint32_t M, uint32_t *tgt) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -413,7 +414,7 @@ __global__ void ph_link_targets_kernel(const uint32_t *nodes, uint32_t n, const 
       uint32_t vid = res_ids[(uint64_t)i * M + k];
       if (vid == self)
         stop = true;
-      else
+      else if (vid < n_store)
         t = vec2node ? vec2node[vid] : vid;
     }
     tgt[(uint64_t)i * M + k] = t;
@@ -688,6 +689,11 @@ void ph_pending_free(phnsw_index *ix) { pending_drop(ix); }
 // proposals by (distance, id): that needs d(a, b) == d(b, a) bit for bit.  The 8-bit PQ table
 // scales by the QUERY's table, so it is for searching a graph built in mode 0 or 1.
 static int symmetric_store(const phnsw_store *s) {
+  if (s->codes16) {
+    ph_set_error("a shared-codebook PQ store is searched, not built on: build the index over "
+                 "phnsw_pq_shared_reconstruct_store (identical distances) and adopt it with phnsw_index_from_layers");
+    return PHNSW_E_UNSUPPORTED;
+  }
   if (s->codes && s->pq_table_f16 == 2) {
     ph_set_error("8-bit PQ tables (phnsw_pq_set_table_mode 2) are asymmetric: build / link in mode 0 or 1, then switch");
     return PHNSW_E_UNSUPPORTED;
@@ -948,7 +954,7 @@ static int link_apply_impl(phnsw_index *ix, uint32_t lft, uint64_t link_count, c
   DevBuf<uint32_t> tgt;
   PH_TRY(tgt.alloc((size_t)n * M));
   hipLaunchKernelGGL(ph_link_targets_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.nodes, n,
-                     L.identity ? nullptr : L.vec2node, res_ids, res_len, M, tgt.p);
+                     L.identity ? nullptr : L.vec2node, (uint32_t)ix->store->n, res_ids, res_len, M, tgt.p);
   PH_HIP(hipGetLastError());
   return apply_proposals(L, tgt.p, res_d, M, out_added);
 }

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(64) void ph_distance_batch_kernel(PhDistArgs da, co
 int ph_distance_batch(const phnsw_store *st, const float *q_dev, uint32_t query_id, const uint32_t *ids_dev, uint32_t k,
                       float *out_dev, hipStream_t s) {
   if (k == 0) return 0;
+  if (st->codes16) {
+    ph_set_error("distance batches over a shared-codebook PQ store are not supported; use its reconstruction store");
+    return PHNSW_E_UNSUPPORTED;
+  }
   PhDistArgs da = ph_dist_args(st);
   if (st->codes) {
     size_t lds = ph_pq_lds_bytes(st);

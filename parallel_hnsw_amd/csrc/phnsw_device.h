@@ -488,3 +488,77 @@ struct DistPQR {
     return finish(d, mask, lane);
   }
 };
+
+// DistPQS<NV>: the reference's quantised comparator (pq.rs:585-599, 767-782): a stored vector IS its
+// reconstruction -- sub-vector j is centroid codes16[v][j] of ONE shared codebook -- and the distance is the
+// full metric on it.  The query sits in registers like DistF32's; a candidate's chunk lane + 64k is fetched
+// through its code (two dependent loads: u16 code, then 16 bytes of the centroid), and the fma chain and the
+// butterfly are chain_partial / wave_sum, so every distance has exactly the bits DistF32 produces on the
+// materialised reconstructions (which is how the graph over the codes is built and how the tests check it).
+template <int NV>
+struct DistPQS {
+  static constexpr bool GLOBAL_TABLE = false;
+  static constexpr bool EARLY = false;
+  float4 qv[NV];
+  uint32_t jk[NV], offk[NV];  // this lane's chunk k: sub-space and float offset inside the centroid
+  __device__ __forceinline__ void lanes(const PhDistArgs &d, uint32_t lane) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      c = c < d.nv4 ? c : d.nv4 - 1u;
+      jk[k] = (4u * c) / d.dsub;
+      offk[k] = (4u * c) % d.dsub;
+    }
+  }
+  __device__ __forceinline__ float4 chunk(const PhDistArgs &d, uint32_t vid, int k) const {
+    const uint32_t code = d.codes16[(uint64_t)vid * d.m + jk[k]];
+    return *(const float4 *)(d.codebook + (uint64_t)code * d.dsub + offk[k]);
+  }
+  __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *, uint32_t lane) {
+    lanes(d, lane);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      uint32_t c = lane + 64u * k;
+      qv[k] = (c < d.nv4) ? ((const float4 *)q)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void prepare_stored(const PhDistArgs &d, uint32_t vid, float *, uint32_t lane) {
+    lanes(d, lane);
+#pragma unroll
+    for (int k = 0; k < NV; k++) qv[k] = (lane + 64u * k < d.nv4) ? chunk(d, vid, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
+    constexpr int U = 4;
+    const bool l2 = d.metric == PHNSW_METRIC_L2, exact = d.nv4 == 64u * NV;
+    float myd = 0.f;
+    uint64_t rem = mask;
+    while (rem) {
+      int l[U];
+      l[0] = __builtin_ctzll(rem);
+      rem &= rem - 1;
+#pragma unroll
+      for (int u = 1; u < U; u++) {
+        l[u] = rem ? __builtin_ctzll(rem) : l[0];
+        rem &= rem ? rem - 1 : 0;
+      }
+      float4 x[U][NV];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t v = rl32(vid, l[u]);
+#pragma unroll
+        for (int k = 0; k < NV; k++) x[u][k] = chunk(d, v, k);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float p;
+        if (exact)
+          p = l2 ? chain_partial<NV, true, true>(x[u], qv, d.nv4, lane) : chain_partial<NV, true, false>(x[u], qv, d.nv4, lane);
+        else
+          p = l2 ? chain_partial<NV, false, true>(x[u], qv, d.nv4, lane) : chain_partial<NV, false, false>(x[u], qv, d.nv4, lane);
+        const float dd = finalize_metric(wave_sum(p), d.metric);
+        if ((int)lane == l[u]) myd = dd;
+      }
+    }
+    return myd;
+  }
+};

@@ -64,6 +64,7 @@ struct PhDistArgs {
   uint32_t ld, nv4;
   int metric;
   const uint8_t *codes;   // [n][m] u8 codes (PQ store)
+  const uint16_t *codes16;  // [n][m] u16 codes over ONE shared codebook [ksub][dsub] (the reference's shape, pq.rs:19-27)
   const float *codebook;  // [m][ksub][dsub]
   uint32_t m, ksub, dsub;
   uint32_t table_f16;  // 1: the per-query table holds IEEE half values (2 bytes per entry)
@@ -75,6 +76,10 @@ struct phnsw_store {
   // product-quantised store (phnsw_store_create_pq): rows == nullptr, dim/ld describe the
   // full vectors a query has
   uint8_t *codes = nullptr;
+  uint16_t *codes16 = nullptr;  // shared-codebook PQ store (pq.hip): codes [n][pq_m], codebook [pq_ksub][pq_dsub]
+  phnsw_store *centroid_store = nullptr;  // ... its centroids as a store of their own and the HNSW over them
+  phnsw_index *centroid_index = nullptr;  //     (HnswQuantizer, pq.rs:29-81)
+  phnsw_search_params quantized_search = {0, 0, 0};
   float *codebook = nullptr;
   uint32_t pq_m = 0, pq_ksub = 0, pq_dsub = 0;
   uint32_t pq_table_f16 = 0;
@@ -251,6 +256,7 @@ static inline PhDistArgs ph_dist_args(const phnsw_store *s) {
   d.nv4 = s->ld / 4;
   d.metric = s->metric;
   d.codes = s->codes;
+  d.codes16 = s->codes16;
   d.codebook = s->codebook;
   d.m = s->pq_m;
   d.ksub = s->pq_ksub;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -268,6 +269,196 @@ extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksu
   return phnsw_store_create_pq_kmeans(full, m, ksub, seed, 0, 0, out);
 } catch (...) { return ph_caught(); }
 
+// ------------------------------------------------------------------ the reference's quantizer shape
+// pq.rs:19-27, 61-81, 261-364: ONE codebook of centroid sub-vectors shared by every sub-space, u16 codes
+// (up to 65 535 centroids -- a per-query table would be m x 65 535 entries, which is why the reference
+// quantises with an HNSW over the centroids and why distances here go through the codes, DistPQS).
+__global__ void ph_ids_to_u16_kernel(const uint32_t *ids, uint64_t n, uint16_t *out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = (uint16_t)ids[i];
+}
+
+__global__ void ph_pq_shared_reconstruct_kernel(const uint16_t *codes, uint64_t n, uint32_t m, uint32_t dsub,
+                                                const float *codebook, float *out, uint32_t ld) {
+  const uint64_t dim = (uint64_t)m * dsub;
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n * dim; x += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = x / dim;
+    const uint32_t c = (uint32_t)(x % dim), j = c / dsub, e = c % dsub;
+    out[i * ld + c] = codebook[(uint64_t)codes[i * m + j] * dsub + e];
+  }
+}
+
+// HnswQuantizer::quantize (pq.rs:61-71) for n vectors [n][m * dsub] resident on the device: every sub-vector is
+// a query against the HNSW over the centroids (quantized_search parameters), its best result is the code
+static int pq_shared_encode_device(const phnsw_store *s, const float *rows_dev, uint64_t n, uint16_t *codes_dev) {
+  const uint64_t total = n * s->pq_m, CH = 1ull << 22;
+  const uint64_t cap = std::min(total, CH);
+  uint32_t *oid = nullptr, *olen = nullptr, *ostat = nullptr;
+  float *od = nullptr;
+  hipError_t e = hipMalloc(&oid, cap * 4);
+  if (e == hipSuccess) e = hipMalloc(&od, cap * 4);
+  if (e == hipSuccess) e = hipMalloc(&olen, cap * 4);
+  if (e == hipSuccess) e = hipMalloc(&ostat, cap * 4);
+  int rc = e == hipSuccess ? 0 : ph_hip_fail(e, "pq quantize staging", __FILE__, __LINE__);
+  std::vector<uint32_t> h_status;
+  for (uint64_t c0 = 0; !rc && c0 < total; c0 += CH) {
+    const uint64_t cnt = std::min(CH, total - c0);
+    rc = ph_search_device(s->centroid_index, rows_dev + c0 * s->pq_dsub, s->pq_dsub, nullptr, cnt, &s->quantized_search, 0,
+                          nullptr, oid, od, olen, nullptr, ostat, 0, 0, 0, /*out_stride=*/1);
+    if (rc) break;
+    hipLaunchKernelGGL(ph_ids_to_u16_kernel, dim3(1024), dim3(256), 0, 0, oid, cnt, codes_dev + c0);
+    h_status.resize(cnt);
+    e = hipMemcpy(h_status.data(), ostat, cnt * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq quantize", __FILE__, __LINE__);
+    for (uint64_t i = 0; !rc && i < cnt; i++)
+      if (h_status[i]) {
+        ph_set_error("pq quantize: sub-vector %llu failed with status %u", (unsigned long long)(c0 + i), h_status[i]);
+        rc = h_status[i] == 4 ? PHNSW_E_MISSING_NODE : PHNSW_E_OVERFLOW;
+      }
+  }
+  for (void *p : {(void *)oid, (void *)od, (void *)olen, (void *)ostat})
+    if (p) hipFree(p);
+  return rc;
+}
+
+extern "C" int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
+                                            const phnsw_build_params *centroid_bp,
+                                            const phnsw_search_params *quantized_search, int centroid_metric,
+                                            phnsw_store **out) try {
+  if (!full || !out || !full->rows || !centroid_bp || !quantized_search || dsub == 0 || (dsub % 4) || (full->dim % dsub) ||
+      full->ld != full->dim || n_centroids == 0 || n_centroids > 65535 || n_centroids > full->n ||
+      quantized_search->number_of_candidates == 0 || quantized_search->number_of_candidates > 1024 ||
+      quantized_search->probe_depth == 0 || centroid_metric < 0 || centroid_metric > 2) {
+    ph_set_error("phnsw_store_create_pq_shared: need an f32 store with dim %% 4 == 0, dsub %% 4 == 0 dividing dim, "
+                 "1 <= n_centroids <= min(65535, n), valid parameters");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(full->device));
+  const uint32_t m = full->dim / dsub;
+  // random_centroids  pq.rs:261-285: the sub-vectors of n_centroids selected vectors, sorted, de-duplicated,
+  // shuffled, truncated
+  std::vector<uint64_t> perm(full->n);
+  for (uint64_t i = 0; i < full->n; i++) perm[i] = i;
+  ph_shuffle_u64(perm.data(), full->n, seed ^ 0x9C0DEB00C5ULL);
+  std::vector<uint32_t> sel(n_centroids);
+  for (uint32_t k = 0; k < n_centroids; k++) sel[k] = (uint32_t)perm[k];
+  std::vector<float> picked((size_t)n_centroids * full->ld);
+  {
+    uint32_t *sel_d = nullptr;
+    float *rows_d = nullptr;
+    hipError_t e = hipMalloc(&sel_d, (size_t)n_centroids * 4);
+    if (e == hipSuccess) e = hipMalloc(&rows_d, picked.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(sel_d, sel.data(), (size_t)n_centroids * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ph_pq_gather_train_kernel, dim3((n_centroids + 3) / 4), dim3(256), 0, 0, full->rows, full->ld, sel_d,
+                         n_centroids, rows_d);
+      e = hipMemcpy(picked.data(), rows_d, picked.size() * 4, hipMemcpyDeviceToHost);
+    }
+    if (sel_d) hipFree(sel_d);
+    if (rows_d) hipFree(rows_d);
+    if (e != hipSuccess) return ph_hip_fail(e, "pq centroid selection", __FILE__, __LINE__);
+  }
+  const size_t cand = (size_t)n_centroids * m;
+  std::vector<uint64_t> order(cand);
+  for (size_t i = 0; i < cand; i++) order[i] = i;
+  auto subv = [&](uint64_t c) { return picked.data() + (c / m) * full->ld + (c % m) * dsub; };
+  auto less = [&](uint64_t a, uint64_t b) {  // OrderedFloat order component by component (pq.rs:277)
+    const float *x = subv(a), *y = subv(b);
+    for (uint32_t e = 0; e < dsub; e++) {
+      if (x[e] < y[e]) return true;
+      if (x[e] > y[e]) return false;
+    }
+    return false;
+  };
+  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return less(a, b) || (!less(b, a) && a < b); });
+  order.erase(std::unique(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return !less(a, b) && !less(b, a); }),
+              order.end());
+  ph_shuffle_u64(order.data(), order.size(), seed ^ 0x5EEDCE17ULL);
+  const uint32_t C = (uint32_t)std::min<size_t>(order.size(), n_centroids);
+  std::vector<float> cb((size_t)C * dsub);
+  for (uint32_t k = 0; k < C; k++) memcpy(cb.data() + (size_t)k * dsub, subv(order[k]), (size_t)dsub * 4);
+
+  phnsw_store *s = new phnsw_store();
+  s->device = full->device;
+  s->n = full->n;
+  s->dim = full->dim;
+  s->ld = full->ld;
+  s->metric = full->metric;
+  s->rows = nullptr;
+  s->pq_m = m;
+  s->pq_ksub = C;
+  s->pq_dsub = dsub;
+  s->quantized_search = *quantized_search;
+  auto fail = [&](int rc) {
+    phnsw_store_destroy(s);
+    return rc;
+  };
+  // CentroidComparator + Hnsw::generate over the centroids + improve_index  pq.rs:306-312
+  int rc = phnsw_store_create(cb.data(), C, dsub, centroid_metric, full->device, &s->centroid_store);
+  if (rc) return fail(rc);
+  std::vector<uint64_t> cids(C);
+  for (uint32_t k = 0; k < C; k++) cids[k] = k;
+  rc = phnsw_build(s->centroid_store, cids.data(), C, centroid_bp, nullptr, nullptr, &s->centroid_index);
+  if (rc) return fail(rc);
+  rc = phnsw_improve_index(s->centroid_index, centroid_bp, NAN, nullptr, nullptr, nullptr);
+  if (rc) return fail(rc);
+  hipError_t e = hipMalloc(&s->codebook, cb.size() * 4);
+  if (e == hipSuccess) e = hipMemcpy(s->codebook, cb.data(), cb.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&s->codes16, (size_t)s->n * m * 2);
+  if (e != hipSuccess) return fail(ph_hip_fail(e, "pq shared alloc", __FILE__, __LINE__));
+  // centroid_quantizer.quantize(&v) for every vector  pq.rs:326-333
+  rc = pq_shared_encode_device(s, full->rows, s->n, s->codes16);
+  if (!rc) {
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq shared encode", __FILE__, __LINE__);
+  }
+  if (rc) return fail(rc);
+  *out = s;
+  return 0;
+} catch (...) { return ph_caught(); }
+
+extern "C" int phnsw_pq_shared_read(const phnsw_store *s, uint16_t *codes, float *codebook) try {
+  if (!s || !s->codes16) {
+    ph_set_error("not a shared-codebook product-quantised store");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  if (codes) PH_HIP(hipMemcpy(codes, s->codes16, (size_t)s->n * s->pq_m * 2, hipMemcpyDeviceToHost));
+  if (codebook) PH_HIP(hipMemcpy(codebook, s->codebook, (size_t)s->pq_ksub * s->pq_dsub * 4, hipMemcpyDeviceToHost));
+  return 0;
+} catch (...) { return ph_caught(); }
+
+// the reconstructions of a shared-codebook store as an f32 store of their own: distances over it have the same
+// bits as over the codes (DistPQS), so the Hnsw over the quantised vectors (pq.rs:336-338) is built on it with
+// the full-precision kernels and adopted over the codes (phnsw_index_from_layers); destroy it afterwards
+extern "C" int phnsw_pq_shared_reconstruct_store(const phnsw_store *s, phnsw_store **out) try {
+  if (!s || !s->codes16 || !out) {
+    ph_set_error("phnsw_pq_shared_reconstruct_store: needs a shared-codebook product-quantised store");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(s->device));
+  float *rows = nullptr;
+  PH_HIP(hipMalloc(&rows, (size_t)s->n * s->ld * 4));
+  hipLaunchKernelGGL(ph_pq_shared_reconstruct_kernel, dim3(4096), dim3(256), 0, 0, s->codes16, s->n, s->pq_m, s->pq_dsub,
+                     s->codebook, rows, s->ld);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    hipFree(rows);
+    return ph_hip_fail(e, "pq shared reconstruct", __FILE__, __LINE__);
+  }
+  phnsw_store *r = new phnsw_store();
+  r->device = s->device;
+  r->rows = rows;
+  r->owns_rows = true;
+  r->n = s->n;
+  r->dim = s->dim;
+  r->ld = s->ld;
+  r->metric = s->metric;
+  *out = r;
+  return 0;
+} catch (...) { return ph_caught(); }
+
 // How the per-query lookup table T[m][ksub] is stored.  0: f32, the
 // reference arithmetic.  1: every entry rounded once to IEEE half.  2: 8-bit entries
 // u = rint((T - min_row) / scale), scale = widest row range / 255; a distance is then
@@ -343,7 +534,7 @@ extern "C" int phnsw_pq_reconstruct(const phnsw_store *s, const uint8_t *codes, 
 } catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub) try {
-  if (!s || !s->codes) {
+  if (!s || (!s->codes && !s->codes16)) {
     ph_set_error("not a product-quantised store");
     return PHNSW_E_INVALID;
   }
@@ -371,7 +562,7 @@ extern "C" int phnsw_pq_read(const phnsw_store *s, uint8_t *codes, float *codebo
 extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *full, const float *queries, uint64_t nq,
                                      const phnsw_search_params *sp, int quantize_query, uint64_t *out_ids,
                                      float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
-  if (!ix || !full || !queries || !sp || !out_ids || !out_d || !out_len || !ix->store->codes || !full->rows ||
+  if (!ix || !full || !queries || !sp || !out_ids || !out_d || !out_len || (!ix->store->codes && !ix->store->codes16) || !full->rows ||
       full->n != ix->store->n || full->dim != ix->store->dim || nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 ||
       sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
     ph_set_error("phnsw_pq_search_batch: need an index over a PQ store, its full-precision store and valid parameters");
@@ -396,7 +587,23 @@ extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *f
   if (e == hipSuccess) e = hipMalloc(&ost, nq * 8);
   if (e == hipSuccess) e = hipMalloc(&ostat, nq * 4);
   const float *qsearch = qd;
-  if (e == hipSuccess && quantize_query) {
+  if (e == hipSuccess && quantize_query && ps->codes16) {
+    // quantizer.quantize(&raw_v) through the HNSW over the centroids, then its reconstruction  pq.rs:351-353
+    uint16_t *qc16 = nullptr;
+    e = hipMalloc(&qc16, (size_t)nq * ps->pq_m * 2);
+    if (e == hipSuccess) e = hipMalloc(&qq, (size_t)nq * full->ld * 4);
+    if (e == hipSuccess) {
+      rc = pq_shared_encode_device(ps, qd, nq, qc16);
+      if (!rc) {
+        hipLaunchKernelGGL(ph_pq_shared_reconstruct_kernel, dim3(1024), dim3(256), 0, 0, qc16, nq, ps->pq_m, ps->pq_dsub,
+                           ps->codebook, qq, full->ld);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        qsearch = qq;
+      }
+    }
+    if (qc16) hipFree(qc16);
+  } else if (e == hipSuccess && quantize_query) {
     e = hipMalloc(&qcodes, (size_t)nq * ps->pq_m);
     if (e == hipSuccess) e = hipMalloc(&qq, (size_t)nq * full->ld * 4);
     if (e == hipSuccess) e = hipMemset(qq, 0, (size_t)nq * full->ld * 4);
@@ -411,7 +618,7 @@ extern "C" int phnsw_pq_search_batch(const phnsw_index *ix, const phnsw_store *f
       qsearch = qq;
     }
   }
-  if (e != hipSuccess) rc = ph_hip_fail(e, "pq search staging", __FILE__, __LINE__);
+  if (e != hipSuccess && !rc) rc = ph_hip_fail(e, "pq search staging", __FILE__, __LINE__);
   if (!rc)
     rc = ph_search_device(ix, qsearch, full->ld, nullptr, nq, sp, 0, nullptr, oid, od, olen, ost, ostat, 0, 0, 0);
   std::vector<uint32_t> h_status(nq);
@@ -474,7 +681,7 @@ extern "C" int phnsw_pq_search_batch_device(const phnsw_index *ix, const phnsw_s
                                             uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
                                             uint32_t *out_stats_dev, uint32_t *status_dev, void *stream) try {
   if (!ix || !full || !queries_dev || !sp || !out_ids_dev || !out_d_dev || !out_len_dev || !status_dev ||
-      !ix->store->codes || !full->rows || full->n != ix->store->n || full->dim != ix->store->dim ||
+      (!ix->store->codes && !ix->store->codes16) || !full->rows || full->n != ix->store->n || full->dim != ix->store->dim ||
       nq > 0xFFFFFFFFull || sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0 ||
       ldq < full->ld || (ldq % 4)) {
     ph_set_error("phnsw_pq_search_batch_device: invalid argument");

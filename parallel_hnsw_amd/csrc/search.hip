@@ -642,6 +642,15 @@ static ph_search_fn pick_kernel_pqr(int capc, int m) {
   return nullptr;
 }
 
+// shared-codebook PQ stores (u16 codes): the query layout is DistF32's, the candidate rows come through the codes
+static ph_search_fn pick_kernel_pqs(int capc, int nv) {
+#define PH_KS(C, N) \
+  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, DistPQS<N>>;
+  PH_KS(2, 1) PH_KS(2, 3) PH_KS(2, 6) PH_KS(8, 1) PH_KS(8, 3) PH_KS(8, 6)
+#undef PH_KS
+  return nullptr;
+}
+
 // nv == 0 selects the product-quantised policy
 static ph_search_fn pick_kernel(int capc, int nv) {
 #define PH_K(C, N) \
@@ -664,7 +673,7 @@ static size_t lds_bytes(int capc, size_t pq_lds) { return (size_t)(5 * capc * 64
 uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds, int pqr_m) {
   int capc = pick_capc(ef), nv = pq ? 0 : pick_nv(nv4);
   if (!capc || (!pq && !nv)) return 0;
-  ph_search_fn fn = pqr_m ? pick_kernel_pqr(capc, pqr_m) : pick_kernel(capc, nv);
+  ph_search_fn fn = pqr_m == -1 ? pick_kernel_pqs(capc, nv) : (pqr_m ? pick_kernel_pqr(capc, pqr_m) : pick_kernel(capc, nv));
   if (!fn) return 0;
   int dev = 0;
   hipGetDevice(&dev);
@@ -706,7 +715,7 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
   uint64_t max_nodes = 0;
   for (auto &l : ix->layers) max_nodes = std::max<uint64_t>(max_nodes, l.n_nodes);
   uint64_t words = (max_nodes + 31) / 32 + 1;
-  const int pqr = pick_pqr(ix->store, pick_capc(ef));
+  const int pqr = ix->store->codes16 ? -1 : pick_pqr(ix->store, pick_capc(ef));  // -1: shared-codebook store
   const bool pqg = ix->store->codes != nullptr && (ph_pq_global_tables() || pqr);  // (the register policy stages its table there)
   uint32_t slots = ph_search_slots(ef, ix->store->ld / 4, ix->store->codes != nullptr,
                                    pqg ? 0 : ph_pq_lds_bytes(ix->store), pqr);
@@ -765,11 +774,12 @@ int ph_search_begin(PhWorkspace &ws, hipStream_t stream) {
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end) {
   const bool pq = ix->store->codes != nullptr;
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
-  const int pqr = pick_pqr(ix->store, capc);
+  const int pqr = ix->store->codes16 ? -1 : pick_pqr(ix->store, capc);
   const size_t pq_lds = pq ? ((pqr || ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
   a.pq_tables = ws.pq_tables;
   a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
-  ph_search_fn fn = (capc && (pq || nv)) ? (pqr ? pick_kernel_pqr(capc, pqr) : pick_kernel(capc, nv)) : nullptr;
+  ph_search_fn fn = nullptr;
+  if (capc && (pq || nv)) fn = pqr == -1 ? pick_kernel_pqs(capc, nv) : (pqr ? pick_kernel_pqr(capc, pqr) : pick_kernel(capc, nv));
   if (!fn) {
     ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);
     return PHNSW_E_UNSUPPORTED;

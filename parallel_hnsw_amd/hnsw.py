@@ -204,8 +204,59 @@ class PqStore(VectorStore):
         return out
 
 
+class SharedPqStore(VectorStore):
+    """the reference's quantizer shape (pq.rs:19-27, 61-81, 261-285): ONE codebook of up to 65535 centroid
+    sub-vectors shared by all sub-spaces, u16 codes, quantize = top-1 of an HNSW search over the centroids"""
+
+    def __init__(self, full, centroid_size, number_of_centroids, seed=0, centroid_bp=None, quantized_search=None,
+                 centroid_metric=METRIC_L2):
+        h = C.c_void_p()
+        cbp = centroid_bp or BuildParameters()
+        qs = quantized_search or SearchParameters()
+        check(lib().phnsw_store_create_pq_shared(full._h, centroid_size, number_of_centroids, seed, C.byref(cbp), C.byref(qs),
+                                                 centroid_metric, C.byref(h)))
+        VectorStore.__init__(self, _handle=h, device=full.device)
+        self.full = full
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().phnsw_pq_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.m, self.ksub, self.dsub = a.value, b.value, c.value
+
+    def codes(self):
+        out = np.empty((self.n, self.m), dtype=np.uint16)
+        check(lib().phnsw_pq_shared_read(self._h, _p(out), None))
+        return out
+
+    def codebook(self):
+        out = np.empty((self.ksub, self.dsub), dtype=np.float32)
+        check(lib().phnsw_pq_shared_read(self._h, None, _p(out)))
+        return out
+
+    def reconstruct_store(self):
+        """the reconstructions as an f32 VectorStore (same distance bits as the code rows)"""
+        h = C.c_void_p()
+        check(lib().phnsw_pq_shared_reconstruct_store(self._h, C.byref(h)))
+        return VectorStore(_handle=h, device=self.device)
+
+
 class QuantizedHnsw:
     """QuantizedHnsw (pq.rs:120-131, 287-364): quantizer + Hnsw over the codes + full comparator"""
+
+    @classmethod
+    def reference_shaped(cls, number_of_centroids, comparator, centroid_size, bp=None, centroid_bp=None,
+                         quantized_search=None, seed=0, centroid_metric=METRIC_L2):
+        """QuantizedHnsw::new(number_of_centroids, comparator, PqBuildParameters{centroids, hnsw, quantized_search})
+        pq.rs:287-344 in its own shape: shared codebook, HNSW quantizer, u16 codes, Hnsw over the quantised
+        vectors (built on their materialised reconstructions -- identical distance bits -- and adopted over
+        the codes)"""
+        self = cls.__new__(cls)
+        self.full = comparator
+        self.store = SharedPqStore(comparator, centroid_size, number_of_centroids, seed, centroid_bp, quantized_search,
+                                   centroid_metric)
+        rec = self.store.reconstruct_store()
+        g = Hnsw.generate(rec, np.arange(comparator.n, dtype=np.uint64), bp or BuildParameters(promote=0))
+        self.hnsw = Hnsw.from_layers(self.store, [(l.nodes, l.neighbors) for l in g.layers], g.build_parameters)
+        del g, rec
+        return self
 
     def __init__(self, number_of_centroids, comparator, bp=None, m=None, seed=0, vids=None, table_f16=False,
                  table_mode=None, kmeans_iters=0, kmeans_sample=0, graph=None):

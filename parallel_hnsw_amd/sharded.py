@@ -26,6 +26,26 @@ from ._lib import check, lib
 from .hnsw import BuildParameters, Hnsw
 
 
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def wait(self):
+        return self.value
+
+
+class _Pending:
+    def __init__(self, work, out, src, comm):
+        self.work, self.out, self.src, self.comm = work, out, src, comm
+
+    def wait(self):
+        import time
+        t0 = time.perf_counter()
+        self.work.wait()  # stream-level: the current stream (libphnsw's null stream) waits for the transfer
+        self.comm.seconds += time.perf_counter() - t0
+        return self.out
+
+
 class TorchComm:
     """all-gather / all-reduce over a torch.distributed group (nccl = RCCL on ROCm, gloo on CPU)"""
 
@@ -36,7 +56,8 @@ class TorchComm:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_gathered = 0
-        self.seconds = 0.0  # wall time inside the collectives (with their synchronisation)
+        self.calls = 0
+        self.seconds = 0.0  # host wall time inside the collectives (enqueue + any wait that blocks the host)
 
     def all_gather(self, t):
         if self.world == 1:
@@ -49,11 +70,29 @@ class TorchComm:
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
         self.dist.all_gather_into_tensor(out, src, group=self.group)
         self.bytes_gathered += out.numel() * out.element_size()
+        self.calls += 1
         if t.is_cuda and not staged:
             torch.cuda.synchronize(t.device)  # libphnsw reads the result outside torch's stream bookkeeping
         out = out.to(t.device) if staged else out
         self.seconds += time.perf_counter() - t0
         return out
+
+    def all_gather_async(self, t):
+        """start the collective and return a handle; handle.wait() orders the CURRENT stream behind it and returns
+        the gathered tensor.  Over RCCL the transfer runs on the communicator's own stream, so kernels enqueued
+        after this call (the next sub-chunk's searches) overlap it; gloo and the 1-GPU rehearsal complete here."""
+        import torch
+        if self.world == 1 or not t.is_cuda or self.dist.get_backend(self.group) == "gloo":
+            return _Done(self.all_gather(t))
+        import time
+        t0 = time.perf_counter()
+        src = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+        work = self.dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        self.bytes_gathered += out.numel() * out.element_size()
+        self.calls += 1
+        self.seconds += time.perf_counter() - t0
+        return _Pending(work, out, src, self)
 
     def all_reduce_sum(self, values, device):
         if self.world == 1:
@@ -182,28 +221,43 @@ class ShardedBuilder:
         count = min(n, first + chunk) - first
         return chunk, first, count
 
-    def _gather(self, t, n):
-        if n < self.SHARD_MIN:
-            return t[:n]
-        return self.comm.all_gather(t)[:n]
+    # A rank's share of a phase is cut into SUBCHUNKS pieces when it is long enough: the all-gather of piece k
+    # is started asynchronously and travels over xGMI while piece k + 1 is being searched.
+    SUBCHUNKS = 4
+    SUB_MIN = 8192
 
-    def _gather_many(self, ts, n):
-        """one collective for several per-node arrays of 4-byte elements (ids, distances, lengths):
-        packed side by side as int32 columns, gathered, split again"""
+    def _phase(self, n, specs, run):
+        """One sharded phase over a list of n work items.  specs: [(width or None, kind)] of the per-item
+        outputs; run(first, count, outs) fills rows [0, count) of the given buffers with the results of items
+        [first, first + count).  Returns the full [n, ...] arrays, identical on every rank."""
+        chunk, first, count = self._range(n)
+        outs = [self.e.empty((chunk,) if w is None else (chunk, w), kind) for w, kind in specs]
         if n < self.SHARD_MIN:
-            return [t[:n] for t in ts]
+            run(first, count, outs)
+            return [o[:n] for o in outs]
         import torch
-        if not all(isinstance(t, torch.Tensor) and t.element_size() == 4 for t in ts):
-            return [self._gather(t, n) for t in ts]
-        cols = [t.view(torch.int32).reshape(t.shape[0], -1) for t in ts]
-        full = self.comm.all_gather(torch.cat(cols, dim=1))[:n]
-        out, at = [], 0
-        for t, c in zip(ts, cols):
-            w = c.shape[1]
-            piece = full[:, at:at + w].contiguous().view(t.dtype)
-            out.append(piece.reshape((n,) + tuple(t.shape[1:])))
-            at += w
-        return out
+        nsub = self.SUBCHUNKS if (hasattr(self.comm, "all_gather_async") and chunk >= self.SUBCHUNKS * self.SUB_MIN) else 1
+        bounds = [chunk * k // nsub for k in range(nsub + 1)]
+        pending = []
+        for k in range(nsub):
+            lo, hi = bounds[k], bounds[k + 1]
+            cnt = max(0, min(count, hi) - lo)
+            if cnt:
+                run(first + lo, cnt, [o[lo:lo + cnt] for o in outs])
+            # the piece's outputs side by side as raw bytes: one collective per piece
+            cols = [o[lo:hi].reshape(hi - lo, -1).contiguous().view(torch.uint8) for o in outs]
+            packed = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+            h = self.comm.all_gather_async(packed) if nsub > 1 else _Done(self.comm.all_gather(packed))
+            pending.append((lo, hi, h, [c.shape[1] for c in cols]))
+        full = [self.e.empty((self.world * chunk,) + tuple(o.shape[1:]), kind) for o, (_, kind) in zip(outs, specs)]
+        for lo, hi, h, widths in pending:
+            g = h.wait().view(self.world, hi - lo, -1)
+            at = 0
+            for f, o, wb in zip(full, outs, widths):
+                piece = g[:, :, at:at + wb].contiguous().view(o.dtype)
+                f.view((self.world, chunk) + tuple(o.shape[1:]))[:, lo:hi] = piece.reshape((self.world, hi - lo) + tuple(o.shape[1:]))
+                at += wb
+        return [f[:n] for f in full]
 
     # generate_layer  lib.rs:675-823
     def generate_layer(self, vids, W):
@@ -211,22 +265,18 @@ class ShardedBuilder:
         if not needs:
             return
         n = len(vids)
-        chunk, first, count = self._range(n)
-        ids, d, ln = self.e.empty((chunk, K), "id"), self.e.empty((chunk, K), "f32"), self.e.empty((chunk,), "id")
-        self.e.layer_init_search(first, count, ids, d, ln)
-        ids_f, d_f, ln_f = self._gather_many([ids, d, ln], n)
-        rows, rows_d = self.e.empty((chunk, W), "id"), self.e.empty((chunk, W), "f32")
-        self.e.layer_seed(ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous(), first, count, rows, rows_d)
-        rows_f, rows_d_f = self._gather_many([rows, rows_d], n)
+        ids_f, d_f, ln_f = self._phase(n, [(K, "id"), (K, "f32"), (None, "id")],
+                                       lambda f, c, o: self.e.layer_init_search(f, c, o[0], o[1], o[2]))
+        ids_f, d_f, ln_f = ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous()
+        rows_f, rows_d_f = self._phase(n, [(W, "id"), (W, "f32")],
+                                       lambda f, c, o: self.e.layer_seed(ids_f, d_f, ln_f, f, c, o[0], o[1]))
         self.e.layer_finish(rows_f.contiguous(), rows_d_f.contiguous())
 
     # link_layer_to_better_neighbors  lib.rs:1070-1154
     def link_layer(self, lft, sp, M):
         n = self.e.layer_nodes(lft)
-        chunk, first, count = self._range(n)
-        ids, d, ln = self.e.empty((chunk, M), "id"), self.e.empty((chunk, M), "f32"), self.e.empty((chunk,), "id")
-        self.e.link_search(lft, sp, M, first, count, ids, d, ln)
-        ids_f, d_f, ln_f = self._gather_many([ids, d, ln], n)
+        ids_f, d_f, ln_f = self._phase(n, [(M, "id"), (M, "f32"), (None, "id")],
+                                       lambda f, c, o: self.e.link_search(lft, sp, M, f, c, o[0], o[1], o[2]))
         return self.e.link_apply(lft, M, ids_f.contiguous(), d_f.contiguous(), ln_f.contiguous())
 
     # stochastic_recall_at  lib.rs:1463-1499
@@ -264,10 +314,9 @@ class ShardedBuilder:
         if not hasattr(self.e, "discover_hits"):
             return self.e.promote_at_layer(lft)
         n = self.e.layer_nodes(lft)
-        chunk, first, count = self._range(n)
-        hit = self.e.empty((chunk,), "id")
-        self.e.discover_hits(lft, self.bp.optimization.search, first, count, hit)
-        return self.e.promote_from_hits(lft, self._gather(hit, n).contiguous())
+        (hit_f,) = self._phase(n, [(None, "id")],
+                               lambda f, c, o: self.e.discover_hits(lft, self.bp.optimization.search, f, c, o[0]))
+        return self.e.promote_from_hits(lft, hit_f.contiguous())
 
     # improve_index_at  lib.rs:1546-1603
     def improve_index_at(self, lft):

@@ -174,6 +174,12 @@ extern "C" {
                                  out: *mut *mut phnsw_store) -> c_int;
     pub fn phnsw_store_create_pq_kmeans(full: *mut phnsw_store, m: u32, ksub: u32, seed: u64, kmeans_iters: u32,
                                         sample: u64, out: *mut *mut phnsw_store) -> c_int;
+    pub fn phnsw_store_create_pq_shared(full: *mut phnsw_store, dsub: u32, n_centroids: u32, seed: u64,
+                                        centroid_bp: *const phnsw_build_params,
+                                        quantized_search: *const phnsw_search_params, centroid_metric: c_int,
+                                        out: *mut *mut phnsw_store) -> c_int;
+    pub fn phnsw_pq_shared_read(s: *const phnsw_store, codes: *mut u16, codebook: *mut c_float) -> c_int;
+    pub fn phnsw_pq_shared_reconstruct_store(s: *const phnsw_store, out: *mut *mut phnsw_store) -> c_int;
     pub fn phnsw_pq_info(s: *const phnsw_store, m: *mut u32, ksub: *mut u32, dsub: *mut u32) -> c_int;
     pub fn phnsw_pq_set_table_mode(s: *mut phnsw_store, mode: c_int) -> c_int;
     pub fn phnsw_pq_set_table_f16(s: *mut phnsw_store, on: c_int) -> c_int;

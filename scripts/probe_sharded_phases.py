@@ -45,6 +45,8 @@ class Timed:
 
 if kind == "clustered":
     store = ph.VectorStore.clustered(n, dim, seed=42, first=0, n_clusters=1000, noise=1.0)
+elif kind == "survey":
+    store = ph.VectorStore.clustered(n, dim, seed=42, first=0, n_clusters=max(1000, n // 1000), noise=0.1 * dim ** 0.5)
 else:
     store = ph.VectorStore.synthetic(n, dim, seed=42)
 bp = ph.BuildParameters()
@@ -81,28 +83,33 @@ class EmuEngine(Timed):
     def __init__(self, eng, w):
         super().__init__(eng)
         self.w = w
-        self.stash = {}
+        self.queue = []
         self.hits_rest = 0
 
     def _run(self, name, total, outs, call):
-        """outs: the rank-0 output tensors; call(first, count, outs)"""
-        chunk = outs[0].shape[0]
+        """outs: rank 0's output views (its whole range: the emulation runs without the sub-chunk pipeline);
+        call(first, count, outs).  The other ranks' blocks are computed untimed and queued, packed the way
+        ShardedBuilder._phase packs them, for EmuComm.all_gather"""
+        whole = total < ph.ShardedBuilder.SHARD_MIN  # short lists run whole on every rank, no collective
+        chunk = total if whole else -(-total // self.w)
         torch.cuda.synchronize()
         t0 = time.time()
         call(0, min(chunk, total), outs)
         torch.cuda.synchronize()
         self.t[name] += time.time() - t0
         self.c[name] += 1
-        rest = [[] for _ in outs]
+        if whole:
+            return
+        blocks = []
         for r in range(1, self.w):
             f = min(total, r * chunk)
             cnt = min(total, f + chunk) - f
-            o2 = [torch.empty_like(o) for o in outs]
-            call(f, cnt, o2)
-            for i, o in enumerate(o2):
-                rest[i].append(o)
-        for i, o in enumerate(outs):
-            self.stash[o.data_ptr()] = rest[i]
+            o2 = [torch.zeros((chunk,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device) for o in outs]
+            if cnt:
+                call(f, cnt, [o[:cnt] for o in o2])
+            cols = [o.reshape(chunk, -1).contiguous().view(torch.uint8) for o in o2]
+            blocks.append(cols[0] if len(cols) == 1 else torch.cat(cols, dim=1))
+        self.queue.append(blocks)
 
     def layer_begin(self, vids, W):
         self.n_layer = len(vids)
@@ -132,7 +139,7 @@ class EmuEngine(Timed):
         self.t["recall_hits"] += time.time() - t0
         self.c["recall_hits"] += 1
         self.hits_rest = 0
-        for r in range(1, self.w):
+        for r in range(1, self.w if sel >= ph.ShardedBuilder.SHARD_MIN else 1):
             f = min(sel, r * count)
             h2, _ = self._e.recall_hits(at, op, f, min(sel, f + count) - f)
             self.hits_rest += h2
@@ -145,18 +152,20 @@ class EmuComm:
 
     def all_gather(self, t):
         self.bytes += t.numel() * t.element_size() * self.world
-        return torch.cat([t] + self.e.stash.pop(t.data_ptr()), 0)
+        return torch.cat([t] + self.e.queue.pop(0), 0)
 
     def all_reduce_sum(self, values, device):
         return [values[0] + self.e.hits_rest]
 
 
 ref_layers = None
-for w in (1, 2, 4, 8):
+for w in [int(x) for x in os.environ.get("EMU_WORLDS", "1,2,4,8").split(",")]:
     e = EmuEngine(ph.GpuEngine(store, bp), w)
     c = EmuComm(e, w)
     torch.cuda.synchronize()
-    ph.ShardedBuilder(e, c).generate(np.arange(n, dtype=np.uint64))
+    sb = ph.ShardedBuilder(e, c)
+    sb.SUBCHUNKS = 1
+    sb.generate(np.arange(n, dtype=np.uint64))
     torch.cuda.synchronize()
     sh = sum(v for k, v in e.t.items() if k in SHARDED)
     rp = sum(v for k, v in e.t.items() if k in REPL)

@@ -338,3 +338,52 @@ def test_baseline_config1_shape():
         np.testing.assert_array_equal(gi, ci)
         np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))
         np.testing.assert_array_equal(gs, cs)
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        n, dim = 40000, 64
+        store = ph.VectorStore.synthetic(n, dim, seed=42, device=rank)
+        eng = ph.GpuEngine(store, ph.BuildParameters(seed=6, max_link_rounds=1), device=torch.device("cuda", rank))
+        comm = ph.TorchComm()
+        b = ph.ShardedBuilder(eng, comm, shard_min=256)
+        b.SUB_MIN = 1024  # the bottom layer's share is cut into pieces whose all-gathers run asynchronously
+        h = b.generate(np.arange(n))
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered, calls=comm.calls,
+                 **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_build_over_rccl(tmp_path):
+    """one process per GPU, torch.distributed 'nccl' (= RCCL over xGMI), asynchronous all-gathers of the
+    sub-chunk pipeline: every rank ends with the graph one GPU builds.  Needs two GPUs; the one-GPU test
+    boxes skip it (the gloo rehearsal above covers the device side there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs (RCCL: one rank per GPU)")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n, dim = 40000, 64
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    ref = ph.Hnsw.generate(store, np.arange(n), ph.BuildParameters(seed=6, max_link_rounds=1))
+    for r in range(world):
+        z = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert int(z["gathered"]) > 0 and int(z["calls"]) > 4
+        for l in range(ref.layer_count()):
+            np.testing.assert_array_equal(z["nb%d" % l], ref._layer(l).neighbors, err_msg="rank %d layer %d" % (r, l))

@@ -260,3 +260,64 @@ def test_register_table_search_equals_the_other_table_placements_and_the_oracle(
     np.testing.assert_array_equal(reg[0], ci)
     np.testing.assert_array_equal(reg[1].view(np.uint32), cd.view(np.uint32))
     np.testing.assert_array_equal(reg[3], cs)
+
+
+def test_reference_shaped_quantizer():
+    """pq.rs's own shape (pq.rs:920-978 scaled down): one shared codebook, u16 codes, HNSW quantizer.
+    * codes: the HNSW over the centroids finds (almost always) the exact nearest centroid;
+    * distances over the code rows == DistF32 over the materialised reconstructions, bit for bit, so a search of
+      the adopted graph over the codes equals the search over the reconstruction store;
+    * QuantizedHnsw::search (quantised query, re-rank, sort) finds the true neighbours."""
+    n, dim, cs, C_ = 4000, 128, 16, 500
+    rows = oracle.synth_rows(0, n, dim)  # random_normed_vec, like the reference's test (pq.rs:959-968)
+    full = ph.VectorStore(rows[:, :dim], metric=ph.METRIC_L2)
+    qh = ph.QuantizedHnsw.reference_shaped(C_, full, cs, bp=ph.BuildParameters(seed=1),
+                                           centroid_bp=ph.BuildParameters(seed=2), quantized_search=ph.SearchParameters(64, 64, 2))
+    st = qh.store
+    assert (st.m, st.dsub) == (dim // cs, cs) and st.ksub <= C_
+    codes, cb = st.codes(), st.codebook()
+    assert codes.dtype == np.uint16 and codes.shape == (n, dim // cs) and codes.max() < st.ksub
+    # centroids are sub-vectors of the data, pairwise distinct (sort + dedup, pq.rs:277-278)
+    assert len({c.tobytes() for c in cb}) == st.ksub
+    subs = rows[:, :dim].reshape(n * (dim // cs), cs)
+    d2 = ((subs[:, None, :] - cb[None, :, :]) ** 2).sum(2) if n * (dim // cs) * st.ksub < 8e6 else None
+    if d2 is None:
+        pick = np.random.default_rng(0).choice(len(subs), 4000, replace=False)
+        d2 = ((subs[pick, None, :] - cb[None, :, :]) ** 2).sum(2)
+        got = codes.reshape(-1)[pick]
+    else:
+        got = codes.reshape(-1)
+    exact = d2.argmin(1)
+    agree = (d2[np.arange(len(got)), got] <= d2[np.arange(len(got)), exact] * (1 + 1e-6)).mean()
+    assert agree > 0.98, agree  # the HNSW quantizer is approximate by design (pq.rs:61-71)
+    # reconstruction store == codebook[codes]
+    rec = st.reconstruct_store()
+    np.testing.assert_array_equal(rec.read().view(np.uint32), cb[codes].reshape(n, dim).view(np.uint32))
+    # the same graph searched over the codes and over the reconstructions: identical bits
+    g2 = ph.Hnsw.from_layers(rec, [(l.nodes, l.neighbors) for l in qh.hnsw.layers])
+    q = oracle.synth_rows(2 ** 32, 150, dim)[:, :dim]
+    for sp in (ph.SearchParameters(64, 64, 2), ph.SearchParameters(300, 100, 3)):
+        a = qh.hnsw.search_batch(queries=q, sp=sp, stats=True)
+        b = g2.search_batch(queries=q, sp=sp, stats=True)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                          y.view(np.uint32) if y.dtype == np.float32 else y)
+    qid = np.arange(0, n, 9, dtype=np.uint64)
+    a = qh.hnsw.search_batch(qids=qid, sp=ph.SearchParameters(64, 64, 2), exclude=qid)
+    b = g2.search_batch(qids=qid, sp=ph.SearchParameters(64, 64, 2), exclude=qid)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # QuantizedHnsw::search with the query quantised like the reference (pq.rs:351-352) and asymmetric
+    gt = np.argsort(((q[:, None, :] - rows[None, :, :dim]) ** 2).sum(2), axis=1)[:, :10]
+    for quantize in (True, False):
+        ids, d, ln = qh.search_batch(q, ph.SearchParameters(128, 128, 4), quantize_query=quantize)
+        assert (np.diff(d[:, :100], axis=1) >= 0).all()  # re-ranked by the full comparator, sorted
+        rec10 = np.mean([len(set(ids[i, :10].tolist()) & set(gt[i].tolist())) / 10 for i in range(len(q))])
+        assert rec10 > 0.1, (quantize, rec10)  # 8 sub-spaces x 500 centroids on iid data is a coarse code: the flow is what is checked
+    # the reference's own assertion on this flow (test_pq_recall, pq.rs:956-978): the Hnsw over the quantised
+    # vectors finds every stored vector again (self-recall of the reference's estimator)
+    assert qh.hnsw.stochastic_recall() >= 0.99
+    # the code rows are searched, not built on: build entry points refuse them with a status, not a fault
+    with pytest.raises(ph.PhnswError) as e:
+        qh.hnsw.improve_neighbors_upto(qh.hnsw.layer_count(), ph.BuildParameters(promote=0, seed=1))
+    assert e.value.code == -7

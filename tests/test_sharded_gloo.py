@@ -187,31 +187,103 @@ def test_range_split_covers_everything():
             assert seen == list(range(n))
 
 
-def test_packed_gather_splits_back_exactly():
-    """_gather_many: int32 ids, float32 distances and int32 lengths travel as one int32 block"""
+def test_phase_packs_pipelines_and_reassembles_exactly():
+    """ShardedBuilder._phase: each piece of a rank's range travels as one byte block (ids, distances and lengths
+    side by side), pieces are gathered asynchronously and land at their global rows -- with and without the
+    sub-chunk pipeline, for 4- and 8-byte ids"""
     import torch
     from parallel_hnsw_amd.sharded import ShardedBuilder
 
-    class TwoRankComm:  # what rank 1 contributes = rank 0's block with every word's bits flipped
-        rank, world = 0, 2
+    for id_dtype in (torch.int32, torch.int64):
+        for world, n, subs in ((2, 37, 1), (3, 100, 4), (2, 64, 4), (4, 1001, 4)):
+            def item(i, M):  # what work item i produces
+                return (torch.arange(M, dtype=id_dtype) + 1000 * i, torch.full((M,), float(i)) + torch.arange(M) / 16.0, i + 7)
 
-        def all_gather(self, t):
-            assert t.dtype == torch.int32 and t.dim() == 2
-            return torch.cat([t, ~t], 0)
+            class Comm:
+                """rank `me` of `world`: the other ranks' blocks are computed on the spot"""
+                def __init__(self, me, builder_of):
+                    self.rank, self.world, self.builder_of, self.asyncs = me, world, builder_of, 0
 
-    class FakeEngine:
-        bp = None
+                def all_gather(self, t):
+                    return torch.cat([self.builder_of(r).block for r in range(world)], 0)
 
-    b = ShardedBuilder(FakeEngine(), TwoRankComm(), shard_min=0)
-    chunk, M = 5, 3
-    ids = torch.arange(chunk * M, dtype=torch.int32).reshape(chunk, M)
-    d = torch.linspace(-1, 1, chunk * M, dtype=torch.float32).reshape(chunk, M)
-    ln = torch.arange(chunk, dtype=torch.int32) + 7
-    n = 8  # the second rank's last two rows fall off
-    gi, gd, gl = b._gather_many([ids, d, ln], n)
-    assert gi.shape == (n, M) and gd.shape == (n, M) and gl.shape == (n,)
-    assert gi.dtype == torch.int32 and gd.dtype == torch.float32 and gl.dtype == torch.int32
-    assert torch.equal(gi[:chunk], ids) and torch.equal(gd[:chunk], d) and torch.equal(gl[:chunk], ln)
-    assert torch.equal(gi[chunk:], (~ids)[: n - chunk])
-    assert torch.equal(gd[chunk:].view(torch.int32), (~d.view(torch.int32))[: n - chunk])
-    assert torch.equal(gl[chunk:], (~ln)[: n - chunk])
+                def all_gather_async(self, t):
+                    self.asyncs += 1
+                    blocks = [self.builder_of(r).block for r in range(world)]
+
+                    class H:
+                        def wait(self_inner):
+                            return torch.cat(blocks, 0)
+                    return H()
+
+            class Engine:
+                bp = None
+
+                def empty(self, shape, kind):
+                    return torch.zeros(shape, dtype=torch.float32 if kind == "f32" else id_dtype)
+
+            M = 3
+            # every rank's packed piece depends only on (rank, piece): precompute them by running the phase's packing
+            # for each rank in turn, piece by piece, with a recording comm
+            results = {}
+            for me in range(world):
+                pieces = []
+
+                class Rec:
+                    rank, world_ = me, world
+
+                    def __init__(self):
+                        self.rank, self.world = me, world
+
+                    def all_gather(self, t):
+                        pieces.append(t.clone())
+                        return torch.cat([t] * world, 0)
+
+                    def all_gather_async(self, t):
+                        pieces.append(t.clone())
+
+                        class H:
+                            def wait(self_inner):
+                                return torch.cat([t] * world, 0)
+                        return H()
+
+                b = ShardedBuilder(Engine(), Rec(), shard_min=0)
+                b.SUBCHUNKS, b.SUB_MIN = subs, 1
+
+                def run(first, count, outs):
+                    for r in range(count):
+                        i, dd, l = item(first + r, M)
+                        outs[0][r], outs[1][r], outs[2][r] = i, dd, l
+                b._phase(n, [(M, "id"), (M, "f32"), (None, "id")], run)
+                results[me] = pieces
+            # now the real thing on rank 0 with a comm that hands out the recorded pieces in order
+            turn = [0]
+
+            class Replay:
+                def __init__(self):
+                    self.rank, self.world = 0, world
+
+                def _next(self):
+                    k = turn[0]
+                    turn[0] += 1
+                    return torch.cat([results[r][k] for r in range(world)], 0)
+
+                def all_gather(self, t):
+                    return self._next()
+
+                def all_gather_async(self, t):
+                    g = self._next()
+
+                    class H:
+                        def wait(self_inner):
+                            return g
+                    return H()
+
+            b = ShardedBuilder(Engine(), Replay(), shard_min=0)
+            b.SUBCHUNKS, b.SUB_MIN = subs, 1
+            gi, gd, gl = b._phase(n, [(M, "id"), (M, "f32"), (None, "id")], run)
+            assert gi.shape == (n, M) and gd.shape == (n, M) and gl.shape == (n,)
+            assert gi.dtype == id_dtype and gd.dtype == torch.float32 and gl.dtype == id_dtype
+            for i in range(n):
+                ei, ed, el = item(i, M)
+                assert torch.equal(gi[i], ei) and torch.equal(gd[i], ed) and int(gl[i]) == el, (world, n, subs, i)
