@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--skip-tight", dest="no_tight", action="store_true", help="skip round 1's dataset / batch cells")
     ap.add_argument("--skip-pq", dest="no_pq", action="store_true", help="skip the BASELINE config-5 (PQ) measurement")
     ap.add_argument("--no-pmc", action="store_true", help="driver: skip the rocprofv3 counter passes")
+    ap.add_argument("--keep-pmc", default="", help="driver: copy the counter CSVs of the passes into this directory")
     ap.add_argument("--role", default="", choices=["", "driver", "worker", "pmc"])
     ap.add_argument("--dump-index", default="", help="worker: serialise the headline index + parameters here")
     ap.add_argument("--index-dir", default="", help="pmc: directory written by --dump-index")
@@ -702,6 +703,10 @@ def pmc_passes(args, tmp, line):
             for c in counters:
                 acc[c] = float(np.mean([by[g[j]][1].get(c, 0.0) for g in groups]))
         print("[bench] pmc pass %s: %d dispatches per launch, %.0f s" % (name, per, time.time() - t0), file=sys.stderr, flush=True)
+        if args.keep_pmc:
+            os.makedirs(args.keep_pmc, exist_ok=True)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                shutil.copy(f, os.path.join(args.keep_pmc, "pmc_%s_counter_collection.csv" % name))
 
     def read_bytes(c, formula):
         rd, r32, r128 = c["TCC_EA0_RDREQ_sum"], c["TCC_EA0_RDREQ_32B_sum"], c["TCC_EA0_RDREQ_128B_sum"]
@@ -749,7 +754,7 @@ def pmc_passes(args, tmp, line):
 # --------------------------------------------------------------------------------------- driver
 
 def passthrough(args):
-    skip = {"role", "dump_index", "index_dir", "no_pmc", "gpus"}
+    skip = {"role", "dump_index", "index_dir", "no_pmc", "gpus", "keep_pmc"}
     out = ["--gpus", str(args.gpus)]
     for k, v in vars(args).items():
         if k in skip:
