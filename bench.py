@@ -392,7 +392,7 @@ def worker(args):
                                            "cache, so this is not an HBM fraction; per rank when sharded"})
         return res, store, index, qstore, run, sp, gt
 
-    def secondary(kind, cells, batch_cells=()):
+    def secondary(kind, cells, batch_cells=(), latency_cell=None):
         """another dataset: build + recall / q/s cells at the headline batch size (isolated launches)"""
         t0 = time.time()
         store = make_store(ph, kind, args.n, args.dim, 0, local)
@@ -410,6 +410,15 @@ def worker(args):
                 {"layers": "%d-%d" % (x["layers"][0], x["layers"][1] - 1) if i else "dense top layers", "ms": round(x["ms"], 3),
                  "distance_evals": x["n_dist"]} for i, x in enumerate(index.dispatches())]
             del qb, gtb
+        if latency_cell:
+            ef, pd = latency_cell
+            run = Runner(index, q, ef_max=ef)
+            sp_ = ph.SearchParameters(ef, ef, pd)
+            out["batch_sweep"] = {"ef": ef, "probe_depth": pd, "cells": [
+                {"queries": b, "kernel_ms": round(run.isolated_ms(sp_, b, reps=5), 3)} for b in (1, 64, 1024) if b <= args.nq]}
+            for c in out["batch_sweep"]["cells"]:
+                c["queries_per_s"] = round(c["queries"] / c["kernel_ms"] * 1e3)
+            del run
         log("%s cells done in %.1f s" % (kind, time.time() - t0))
         del index, store, q, gtq
         torch.cuda.empty_cache()
@@ -432,7 +441,8 @@ def worker(args):
         torch.cuda.empty_cache()
         if not args.no_tight and args.dataset != "tight":
             # round 1's headline configuration (its dataset, its ef 104 / probe_depth 8, 10 000 and 100 000-query batches)
-            extras["round1_config"] = secondary("tight", [(104, 104, 8), (128, 128, 2), (128, 128, 8)], [(100_000, 104, 8)])
+            extras["round1_config"] = secondary("tight", [(104, 104, 8), (128, 128, 2), (128, 128, 8)], [(100_000, 104, 8)],
+                                                latency_cell=(104, 8))
         if not args.no_iid and args.dataset != "iid":
             extras["iid"] = secondary("iid", LITERAL)
 

@@ -157,7 +157,7 @@ __device__ __forceinline__ float row_partial(const float4 *__restrict__ row, con
 
 // distances of the query to the (up to 64) rows whose ids sit in the lanes flagged by
 // `mask`; 4 rows in flight; the result lands in the lane that held the id
-template <int NV>
+template <int NV, int U>
 __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
                                                  bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
                                                  uint32_t lane);
@@ -186,35 +186,81 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *ids, const f
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
-template <int NV>
+// wave_sum of FOUR rows at once: the first two butterfly steps fold the four registers into one
+// (v_permlane32_swap / v_permlane16_swap, gfx950: a lane keeps the step of the row its 16-lane group will
+// hold), the last four run once on that register with DPP moves -- 7 shuffles instead of 24, every sum formed
+// from the same operands in the same tree as wave_sum (f32 add is commutative).  Afterwards lanes 0-15 hold
+// row 0's sum, 16-31 row 2's, 32-47 row 1's, 48-63 row 3's.
+__device__ __forceinline__ float wave_sum4(float p0, float p1, float p2, float p3) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p2), __float_as_uint(p3), false, false);
+  const float f0 = __uint_as_float(a[0]) + __uint_as_float(a[1]);  // lanes < 32: row 0, >= 32: row 1
+  const float f1 = __uint_as_float(b[0]) + __uint_as_float(b[1]);  // lanes < 32: row 2, >= 32: row 3
+  auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(f0), __float_as_uint(f1), false, false);
+  float v = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+  int t = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xF, 0xF, true);  // row_ror:8
+  v += __uint_as_float((uint32_t)t);
+  const int o = (int)__float_as_uint(v);
+  t = __builtin_amdgcn_update_dpp(o, o, 0x114, 0xF, 0xA, false);  // row_shr:4 into lanes 4-7, 12-15
+  t = __builtin_amdgcn_update_dpp(t, o, 0x104, 0xF, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11
+  v += __uint_as_float((uint32_t)t);
+  t = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  v += __uint_as_float((uint32_t)t);
+  t = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  v += __uint_as_float((uint32_t)t);
+  return v;
+}
+
+template <int NV, int U>
 __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
                                                  bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
                                                  uint32_t lane) {
-  // 4 rows in flight per wave (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster)
-#ifndef PH_ROWS_IN_FLIGHT
-#define PH_ROWS_IN_FLIGHT 4
-#endif
-  constexpr int U = PH_ROWS_IN_FLIGHT;
+  // U rows in flight per wave: 4 for throughput (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster on full
+  // batches); the latency kernels of small batches take 12 (one load round per hop instead of four)
   float myd = 0.f;
-  uint64_t rem = mask;
-  while (rem) {
-    int l[U];
-    l[0] = __builtin_ctzll(rem);
-    rem &= rem - 1;
-#pragma unroll
-    for (int u = 1; u < U; u++) {
-      l[u] = rem ? __builtin_ctzll(rem) : l[0];  // short tail: recompute row l[0] (same value)
-      rem &= rem ? rem - 1 : 0;
-    }
+  const uint32_t m = __popcll(mask);
+  if (m == 0) return myd;
+  // The candidates are compacted first: candidate number k (in lane order) leaves the byte offset of its row in
+  // lane k (ds_permute), so that round r simply reads lanes r*U .. r*U + U-1 -- no bit scans, and the 64-bit
+  // address arithmetic of a row is one v_mad_u64_u32 per lane instead of scalar multiplies per row.
+  const bool cand = (mask >> lane) & 1ull;
+  const uint32_t myrank = __popcll(mask & lanemask_lt(lane));
+  const uint64_t off = (uint64_t)vid * ((uint64_t)ld * 4u);
+  const int dst = (int)((cand ? myrank : 63u) << 2);  // non-candidates park in lane 63 (never read: m <= 63 there)
+  uint32_t olo = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)off);
+  uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)(off >> 32));
+  if (m == 64) {  // every lane is a candidate: the permutation is the identity
+    olo = (uint32_t)off;
+    ohi = (uint32_t)(off >> 32);
+  }
+  for (uint32_t base = 0; base < m; base += U) {
     const float4 *r[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) r[u] = (const float4 *)(vecs + (uint64_t)rl32(vid, l[u]) * ld);
+    for (int u = 0; u < U; u++) {
+      const uint32_t k = min(base + (uint32_t)u, m - 1u);  // short tail: the last row again (same value, unused)
+      const uint64_t o = ((uint64_t)rl32(ohi, (int)k) << 32) | rl32(olo, (int)k);
+      r[u] = (const float4 *)((const char *)vecs + o);
+    }
     float p[U];
     rows_partial<NV, U>(r, qv, nv4, lane, l2, p);
+    const uint32_t mine = myrank - base;  // < U when this is the lane's round
+    if constexpr (U % 4 == 0) {
+      // row u of a group of four ends in lanes {0, 32, 16, 48}[u] + 0..15 (wave_sum4): every candidate lane
+      // fetches its own row's sum with one ds_bpermute
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      float d = finalize_metric(wave_sum(p[u]), metric);
-      if ((int)lane == l[u]) myd = d;
+      for (int g = 0; g < U; g += 4) {
+        const float d4 = finalize_metric(wave_sum4(p[g], p[g + 1], p[g + 2], p[g + 3]), metric);
+        const uint32_t u = (mine - g) & 3u;
+        const uint32_t src = ((u & 1u) << 5) | ((u & 2u) << 3);  // 0, 32, 16, 48
+        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)__float_as_uint(d4)));
+        if (cand && mine >= (uint32_t)g && mine < (uint32_t)g + 4u) myd = got;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float d = finalize_metric(wave_sum(p[u]), metric);
+        if (cand && mine == (uint32_t)u) myd = d;
+      }
     }
   }
   return myd;
@@ -226,7 +272,7 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
 //   DistPQ:      product-quantised store: a per-query table T[m][ksub] in LDS
 //                (T[j][k] = <q_sub_j, c_jk> or |q_sub_j - c_jk|^2), candidates = u8 code
 //                rows, one LANE per candidate, distance = sum_j T[j][code_j] added in j order.
-template <int NV>
+template <int NV, int U = 4>
 struct DistF32 {
   static constexpr bool GLOBAL_TABLE = false;
   static constexpr bool EARLY = false;
@@ -242,7 +288,7 @@ struct DistF32 {
     prepare_raw(d, d.vecs + (uint64_t)vid * d.ld, lds, lane);
   }
   __device__ __forceinline__ float batch(const PhDistArgs &d, uint64_t mask, uint32_t vid, uint32_t lane) const {
-    return batch_distances<NV>(d.vecs, d.ld, d.nv4, d.metric, d.metric == PHNSW_METRIC_L2, qv, mask, vid, lane);
+    return batch_distances<NV, U>(d.vecs, d.ld, d.nv4, d.metric, d.metric == PHNSW_METRIC_L2, qv, mask, vid, lane);
   }
 };
 

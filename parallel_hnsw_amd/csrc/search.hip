@@ -613,6 +613,14 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   ph_search_body<CAPC, Dist>(a);
 }
 
+// Small batches leave most of the chip idle and finish with their slowest query: their kernels keep 12 rows in
+// flight per wave (one load round per hop instead of four) at one or two waves per SIMD.  Same arithmetic per
+// row, so the same results.
+template <int CAPC, int NV>
+__global__ __launch_bounds__(64, 1) void ph_search_kernel_lat(PhSearchArgs a) {
+  ph_search_body<CAPC, DistF32<NV, 12>>(a);
+}
+
 // the register-table policy keeps a whole lookup table in VGPRs: two waves per SIMD is its register budget
 template <int CAPC, int M>
 __global__ __launch_bounds__(64, 2) void ph_search_kernel_pqr(PhSearchArgs a) {
@@ -651,6 +659,15 @@ static ph_search_fn pick_kernel_pqs(int capc, int nv) {
   return nullptr;
 }
 
+#define PH_LATENCY_MAX 1024u  // batches up to this many queries run the latency kernels (PHNSW_NO_LAT=1: never)
+static ph_search_fn pick_kernel_lat(int capc, int nv) {
+#define PH_KL(C, N) \
+  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel_lat<C, N>;
+  PH_KL(2, 1) PH_KL(2, 3) PH_KL(8, 1) PH_KL(8, 3)
+#undef PH_KL
+  return nullptr;
+}
+
 // nv == 0 selects the product-quantised policy
 static ph_search_fn pick_kernel(int capc, int nv) {
 #define PH_K(C, N) \
@@ -674,6 +691,7 @@ uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds, int 
   int capc = pick_capc(ef), nv = pq ? 0 : pick_nv(nv4);
   if (!capc || (!pq && !nv)) return 0;
   ph_search_fn fn = pqr_m == -1 ? pick_kernel_pqs(capc, nv) : (pqr_m ? pick_kernel_pqr(capc, pqr_m) : pick_kernel(capc, nv));
+  if (pqr_m == -2) fn = pick_kernel_lat(capc, nv);
   if (!fn) return 0;
   int dev = 0;
   hipGetDevice(&dev);
@@ -780,6 +798,12 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
   ph_search_fn fn = nullptr;
   if (capc && (pq || nv)) fn = pqr == -1 ? pick_kernel_pqs(capc, nv) : (pqr ? pick_kernel_pqr(capc, pqr) : pick_kernel(capc, nv));
+  // small batches of f32 queries: the latency kernels, when the shape has one
+  int lat = 0;
+  if (!pq && !pqr && a.nq <= PH_LATENCY_MAX && !getenv("PHNSW_NO_LAT") && pick_kernel_lat(capc, nv)) {
+    fn = pick_kernel_lat(capc, nv);
+    lat = -2;
+  }
   if (!fn) {
     ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);
     return PHNSW_E_UNSUPPORTED;
@@ -789,7 +813,7 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   a.ovf = ws.ovf;
   a.ovf_cap = ws.ovf_cap;
   a.counter = ws.counter;
-  uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds, pqr), ws.n_slots);
+  uint32_t slots = std::min<uint32_t>(ph_search_slots(std::max(a.ef, a.cap_max), a.dist.nv4, pq, pq_lds, lat ? lat : pqr), ws.n_slots);
   uint32_t grid = (uint32_t)std::min<uint64_t>(slots, a.nq);
   if (grid == 0) return 0;
   PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));

@@ -8,7 +8,7 @@ mode, ef, pd = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 nq = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
 n = 1_000_000
 dev = torch.device("cuda", 0)
-noise = 0.1 * 768 ** 0.5
+noise = float(os.environ.get("PROBE_NOISE", 0.1 * 768 ** 0.5))
 store = ph.VectorStore.clustered(n, 768, seed=42, n_clusters=1000, noise=noise)
 q = ph.VectorStore.clustered(nq, 768, seed=42, first=2 ** 32, n_clusters=1000, noise=noise)
 h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters())

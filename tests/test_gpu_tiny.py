@@ -105,3 +105,21 @@ def test_layers_that_are_not_nested_fall_back():
         with pytest.raises(ph.PhnswError) as e2:
             h.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2))
     assert e1.value.code == e2.value.code
+
+
+def test_latency_kernels_equal_throughput_kernels():
+    """batches of <= 1024 queries run kernels with 12 rows in flight per wave (PHNSW_NO_LAT=1: the 4-row
+    throughput kernels): same rows, same arithmetic, same results"""
+    n, dim = 20000, 768
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters(seed=9, max_link_rounds=1))
+    q = oracle.synth_rows(2 ** 32, 700, dim)[:, :dim]
+    for sp in (ph.SearchParameters(100, 100, 4), ph.SearchParameters(300, 300, 2)):
+        lat = h.search_batch(queries=q, sp=sp, stats=True)
+        os.environ["PHNSW_NO_LAT"] = "1"
+        try:
+            thr = h.search_batch(queries=q, sp=sp, stats=True)
+        finally:
+            del os.environ["PHNSW_NO_LAT"]
+        same(lat, thr)
