@@ -243,13 +243,13 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       for (;;) {
         // visit_queue.pop(): smallest (d,id) among not yet expanded nodes  lib.rs:191,243-244
         int pop = -1;
-#pragma unroll
-        for (int c = 0; c < CAPC; c++) {
-          if (pop < 0 && 64u * (c + 1) > scan_from) {
-            uint32_t i = lane + 64u * c;
-            bool f = i < qlen && !(Qid[i] & EXPF);
-            uint64_t b = __ballot(f);
-            if (b) pop = 64 * c + __builtin_ctzll(b);
+        for (uint32_t c = scan_from >> 6; 64u * c < qlen; c++) {
+          const uint32_t i = lane + 64u * c;
+          const bool f = i < qlen && !(Qid[i] & EXPF);
+          const uint64_t b = __ballot(f);
+          if (b) {
+            pop = (int)(64u * c) + __builtin_ctzll(b);
+            break;
           }
         }
         uint32_t cur;
@@ -368,9 +368,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           // below it, i.e. into its own chunk or the one above -- both already read.  One chunk of the
           // queue is in registers at a time (a wave's LDS reads and writes execute in program order).
           // What falls past `ef` is spilled.
-#pragma unroll
-          for (int c = CAPC - 1; c >= 0; c--) {
-            if ((uint32_t)c < c_first || 64u * c >= qlen) continue;
+          for (int c = (int)((qlen - 1u) >> 6); c >= (int)c_first; c--) {
             const uint32_t i = lane + 64u * c;
             const bool has = i < qlen;
             const uint32_t qi = has ? Qid[i] : PH_EMPTY32;
