@@ -238,15 +238,16 @@ void ph_tiny_free(PhWorkspace &ws) {
   ws.tiny_d_bytes = ws.tiny_nbr_bytes = ws.tiny_member_bytes = 0;
 }
 
-// Which leading layers run densely.  The tile pass costs 2*dim flop per (query, node) at the f32
-// vector rate, the per-hop path one row gather per evaluation at ~40 GB/s per CU: per query the
-// table of a layer of n nodes costs about what n/24 gathered evaluations do.  closest_nodes
-// evaluates several times number_of_candidates nodes per layer (7x at ef 104 / probe_depth 8), so
-// a layer is taken while n <= 128 * ef (and <= PH_TINY_MAX_NODES).  PHNSW_TINY_MAX overrides.
+// Which leading layers run densely.  Measured at 1M x 768 (100 000 queries): the tile pass costs 0.030 us per
+// (query, node), a table lookup on the walk 0.08 us, a gathered evaluation 0.28-0.35 us; closest_nodes evaluates
+// about 7 x number_of_candidates nodes of a layer it cannot exhaust.  A layer of n nodes is therefore worth a
+// table when n * 0.030 < 7 * ef * 0.2, i.e. n <= 48 * ef (and <= PH_TINY_MAX_NODES): at ef 104 the 7 000-node layer
+// of a 1M index stays on the per-hop path, at ef >= 150 (and in every build round, ef 300) it is tabulated.
+// PHNSW_TINY_MAX overrides.
 uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t ef) {
   const bool off = getenv("PHNSW_NO_TINY") != nullptr;  // tests compare both paths
   if (off || !ix->store->rows || ix->store->ld / 4 > 384) return 0;
-  uint64_t cap = std::min<uint64_t>(PH_TINY_MAX_NODES, 128ull * ef);
+  uint64_t cap = std::min<uint64_t>(PH_TINY_MAX_NODES, 48ull * ef);
   if (const char *e = getenv("PHNSW_TINY_MAX"))
     if (atoi(e) > 0) cap = std::min<uint64_t>(PH_TINY_MAX_NODES, (uint64_t)atoi(e));
   uint32_t T = 0;
