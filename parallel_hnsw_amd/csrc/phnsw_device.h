@@ -168,19 +168,30 @@ __device__ __forceinline__ float finalize_metric(float r, int metric) {
   return sqrtf(r);                                                    // lib.rs:2436
 }
 
-// partition_point over the sorted (d,id) queue held in LDS
+// partition_point over the sorted (d,id) queue held in LDS.  `len` is the same in every lane, so the halving
+// loop is scalar control flow with one select per step (no divergent branches); every lane may call it, whatever
+// its key.
 __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *ids, const float *ds, uint32_t len,
                                                     uint64_t key) {
-  uint32_t lo = 0, hi = len;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    uint64_t k = mkkey(ds[mid], ids[mid]);
-    if (k < key)
-      lo = mid + 1;
-    else
-      hi = mid;
+  if (len == 0) return 0;
+  uint32_t base = 0, n = len;
+  while (n > 1) {
+    const uint32_t half = n >> 1;
+    const uint32_t probe = base + half - 1;
+    base = mkkey(ds[probe], ids[probe]) < key ? base + half : base;
+    n -= half;
   }
-  return lo;
+  return base + (mkkey(ds[base], ids[base]) < key ? 1u : 0u);
+}
+
+// minimum over the wave, in every lane (and uniform): four DPP rotations inside the 16-lane rows, then the four
+// row minima through SGPRs
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));  // row_ror:8
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false));  // row_ror:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false));  // row_ror:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false));  // row_ror:1
+  return min(min(rl32(v, 0), rl32(v, 16)), min(rl32(v, 32), rl32(v, 48)));
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -211,29 +222,11 @@ __device__ __forceinline__ float wave_sum4(float p0, float p1, float p2, float p
   return v;
 }
 
+// one round of batch_distances: candidates base .. base+U-1 (in lane order) of the compacted list
 template <int NV, int U>
-__device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
-                                                 bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
-                                                 uint32_t lane) {
-  // U rows in flight per wave: 4 for throughput (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster on full
-  // batches); the latency kernels of small batches take 12 (one load round per hop instead of four)
-  float myd = 0.f;
-  const uint32_t m = __popcll(mask);
-  if (m == 0) return myd;
-  // The candidates are compacted first: candidate number k (in lane order) leaves the byte offset of its row in
-  // lane k (ds_permute), so that round r simply reads lanes r*U .. r*U + U-1 -- no bit scans, and the 64-bit
-  // address arithmetic of a row is one v_mad_u64_u32 per lane instead of scalar multiplies per row.
-  const bool cand = (mask >> lane) & 1ull;
-  const uint32_t myrank = __popcll(mask & lanemask_lt(lane));
-  const uint64_t off = (uint64_t)vid * ((uint64_t)ld * 4u);
-  const int dst = (int)((cand ? myrank : 63u) << 2);  // non-candidates park in lane 63 (never read: m <= 63 there)
-  uint32_t olo = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)off);
-  uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)(off >> 32));
-  if (m == 64) {  // every lane is a candidate: the permutation is the identity
-    olo = (uint32_t)off;
-    ohi = (uint32_t)(off >> 32);
-  }
-  for (uint32_t base = 0; base < m; base += U) {
+__device__ __forceinline__ void distance_round(const float *__restrict__ vecs, uint32_t nv4, int metric, bool l2,
+                                               const float4 (&qv)[NV], uint32_t olo, uint32_t ohi, uint32_t m, uint32_t base,
+                                               bool cand, uint32_t myrank, uint32_t lane, float &myd) {
     const float4 *r[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -262,6 +255,51 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
         if (cand && mine == (uint32_t)u) myd = d;
       }
     }
+}
+
+template <int NV, int U>
+__device__ __forceinline__ float batch_distances(const float *__restrict__ vecs, uint32_t ld, uint32_t nv4, int metric,
+                                                 bool l2, const float4 (&qv)[NV], uint64_t mask, uint32_t vid,
+                                                 uint32_t lane) {
+  // U rows in flight per wave: 4 for throughput (8 was measured: 183 VGPRs, 2 waves/SIMD, no faster on full
+  // batches); the latency kernels of small batches take 12 (one load round per hop instead of four)
+  float myd = 0.f;
+  const uint32_t m = __popcll(mask);
+  if (m == 0) return myd;
+  // The candidates are compacted first: candidate number k (in lane order) leaves the byte offset of its row in
+  // lane k (ds_permute), so that round r simply reads lanes r*U .. r*U + U-1 -- no bit scans, and the 64-bit
+  // address arithmetic of a row is one v_mad_u64_u32 per lane instead of scalar multiplies per row.
+  const bool cand = (mask >> lane) & 1ull;
+  const uint32_t myrank = __popcll(mask & lanemask_lt(lane));
+  const uint64_t off = (uint64_t)vid * ((uint64_t)ld * 4u);
+  const int dst = (int)((cand ? myrank : 63u) << 2);  // non-candidates park in lane 63 (never read: m <= 63 there)
+  uint32_t olo = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)off);
+  uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)(off >> 32));
+  if (m == 64) {  // every lane is a candidate: the permutation is the identity
+    olo = (uint32_t)off;
+    ohi = (uint32_t)(off >> 32);
+  }
+  if constexpr (U == 0) {
+    // latency kernels: as few load rounds as the hop allows -- 24 rows in flight when more than 12 remain, else
+    // 12, else 4 (a round computes all its U rows whatever the count)
+    uint32_t base = 0;
+    while (base < m) {
+      const uint32_t left = m - base;
+      constexpr int UBIG = NV <= 3 ? 24 : 12;  // 24 rows of 6 float4 per lane would not fit the register file
+      if (left > 12u && UBIG > 12) {
+        distance_round<NV, UBIG>(vecs, nv4, metric, l2, qv, olo, ohi, m, base, cand, myrank, lane, myd);
+        base += (uint32_t)UBIG;
+      } else if (left > 4u) {
+        distance_round<NV, 12>(vecs, nv4, metric, l2, qv, olo, ohi, m, base, cand, myrank, lane, myd);
+        base += 12u;
+      } else {
+        distance_round<NV, 4>(vecs, nv4, metric, l2, qv, olo, ohi, m, base, cand, myrank, lane, myd);
+        base += 4u;
+      }
+    }
+  } else {
+    for (uint32_t base = 0; base < m; base += U)
+      distance_round<NV, U>(vecs, nv4, metric, l2, qv, olo, ohi, m, base, cand, myrank, lane, myd);
   }
   return myd;
 }

@@ -37,6 +37,20 @@
 
 #include "phnsw_device.h"
 
+// -DPH_HOP_PROFILE: a debugging build that prints, per layer of every query, where the hops' time went
+// (100 MHz ticks of s_memrealtime; each phase ends with a forced wait).  Never part of libphnsw.so proper.
+#ifdef PH_HOP_PROFILE
+#define PH_TICK(k)                                   \
+  {                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");   \
+    const uint64_t t_now = wall_clock64();           \
+    tprof[k] += t_now - t_last;                      \
+    t_last = t_now;                                  \
+  }
+#else
+#define PH_TICK(k)
+#endif
+
 template <int CAPC, class Dist>
 __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   extern __shared__ uint32_t smem[];
@@ -240,21 +254,27 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       // every queue entry below scan_from has been expanded: the pop scan starts at its 64-entry chunk,
       // and a hop's merge touches only the chunks from its first insertion point on
       uint32_t scan_from = 0;
+#ifdef PH_HOP_PROFILE
+      uint64_t tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint64_t t_last = wall_clock64();
+      const uint32_t hops_before = n_hops, dist_before = n_dist;
+#endif
       for (;;) {
         // visit_queue.pop(): smallest (d,id) among not yet expanded nodes  lib.rs:191,243-244
         int pop = -1;
+        uint32_t cur = 0;
         for (uint32_t c = scan_from >> 6; 64u * c < qlen; c++) {
           const uint32_t i = lane + 64u * c;
-          const bool f = i < qlen && !(Qid[i] & EXPF);
-          const uint64_t b = __ballot(f);
+          const uint32_t e = i < qlen ? Qid[i] : EXPF;
+          const uint64_t b = __ballot(!(e & EXPF));
           if (b) {
-            pop = (int)(64u * c) + __builtin_ctzll(b);
+            const int pl = __builtin_ctzll(b);
+            pop = (int)(64u * c) + pl;
+            cur = rl32(e, pl);
             break;
           }
         }
-        uint32_t cur;
         if (pop >= 0) {
-          cur = Qid[pop];
           if (lane == 0) Qid[pop] = cur | EXPF;
         } else {
           if (ovf_n == 0) break;
@@ -288,6 +308,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
         cur &= IDM;
         n_hops++;
+        PH_TICK(0)
 
         // get_neighbors(next) + filter(!visited)  lib.rs:195-198
         uint32_t nb = PH_EMPTY32;
@@ -299,6 +320,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           if (valid) v = identity ? nb : L.nodes[nb];
           dist.prefetch(a.dist, valid, v, lane);
         }
+        PH_TICK(1)
         bool fresh = false;
         if (nb < L.n_nodes) {
           uint32_t bit = 1u << (nb & 31);
@@ -308,6 +330,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         const uint64_t fm = __ballot(fresh);
         const uint32_t m = __popcll(fm);
         n_dist += m;
+        PH_TICK(2)
 
         // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202 -- in a dense top
         // layer the value was computed by the tile pass (same bits) and is looked up
@@ -323,6 +346,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           myd = dist.batch(a.dist, fm, vid, lane);
         }
 
+        PH_TICK(3)
         // candidates.merge_pairs(sorted batch)  lib.rs:206,226 / priority_queue.rs:109-144,
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
         // (visited), so final slot = (#queue keys below) + (#batch keys below).
@@ -346,56 +370,92 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         bool did = im != 0;
         if (!im && m >= 2) did = __ballot(fresh && myd == dtail) != 0;
         if (im) {
-          if (ins) pos = lds_lower_bound(Qid, Qd, qlen, key);
+          pos = lds_lower_bound(Qid, Qd, qlen, key);  // every lane searches (uniform trip count); only `ins` lanes use it
           // queue entries below the smallest insertion point stay where they are: their chunks are
           // neither read nor rewritten
-          pos_min = ins ? pos : 0xFFFFFFFFu;
-#pragma unroll
-          for (int sft = 32; sft >= 1; sft >>= 1) pos_min = min(pos_min, (uint32_t)__shfl_xor(pos_min, sft));
-          const uint32_t c_first = pos_min >> 6;
-          // rank of each entering element among the entering elements
+          pos_min = wave_min_u32(ins ? pos : 0xFFFFFFFFu);
+          const int c_first = (int)(pos_min >> 6);
+          PH_TICK(5)
+          // Shift the queue in place, TOP chunks first and two 64-entry chunks per pass: an entry moves up by the
+          // number of entering keys below it, i.e. into its own chunk or the one above -- both already in
+          // registers or already rewritten (a wave's LDS reads and writes execute in program order).  One loop over
+          // the entering keys serves both chunks and, in the first pass, the rank of each entering key among the
+          // entering keys.  What falls past `ef` is spilled.
           uint32_t rank = 0;
-          {
+          bool first_pass = true;
+          for (int c = (int)((qlen - 1u) >> 6); c >= c_first; c -= 2) {
+            const bool two = c > c_first;  // chunk c-1 belongs to this pass (it is a full chunk)
+            const uint32_t i1 = lane + 64u * (uint32_t)c, i0 = i1 - 64u;
+            const bool has1 = i1 < qlen;
+            const uint32_t qi1 = has1 ? Qid[i1] : PH_EMPTY32;
+            const float qd1 = has1 ? Qd[i1] : PH_FMAX;
+            const uint64_t qk1 = has1 ? mkkey(qd1, qi1) : KEY_NONE;
+            uint32_t qi0 = PH_EMPTY32;
+            float qd0 = PH_FMAX;
+            if (two) {
+              qi0 = Qid[i0];
+              qd0 = Qd[i0];
+            }
+            const uint64_t qk0 = two ? mkkey(qd0, qi0) : KEY_NONE;
+            uint32_t sh1 = 0, sh0 = 0;
+            uint64_t rem = im;
+            if (first_pass) {
+              while (rem) {
+                const int j = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                const uint64_t kj = rl64(key, j);
+                rank += (kj < key) ? 1u : 0u;
+                sh1 += (kj < qk1) ? 1u : 0u;
+                sh0 += (kj < qk0) ? 1u : 0u;
+              }
+              first_pass = false;
+            } else {
+              while (rem) {
+                const int j = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                const uint64_t kj = rl64(key, j);
+                sh1 += (kj < qk1) ? 1u : 0u;
+                sh0 += (kj < qk0) ? 1u : 0u;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // both chunks are in registers before either is overwritten
+            const uint32_t np1 = i1 + sh1, np0 = i0 + sh0;
+            if (has1 && np1 < ef) {
+              Qid[np1] = qi1;
+              Qd[np1] = qd1;
+            }
+            if (two && np0 < ef) {
+              Qid[np0] = qi0;
+              Qd[np0] = qd0;
+            }
+            if (qlen + 64u > ef) {  // only a queue within 64 entries of its capacity can push anything out
+              const bool spill1 = has1 && np1 >= ef;
+              const uint64_t sm1 = __ballot(spill1);
+              if (sm1) {
+                const uint32_t at = ovf_n + __popcll(sm1 & lt);
+                if (spill1 && at < a.ovf_cap) ovf[at] = make_uint2(qi1, __float_as_uint(qd1));
+                ovf_n += __popcll(sm1);
+              }
+              const bool spill0 = two && np0 >= ef;
+              const uint64_t sm0 = __ballot(spill0);
+              if (sm0) {
+                const uint32_t at = ovf_n + __popcll(sm0 & lt);
+                if (spill0 && at < a.ovf_cap) ovf[at] = make_uint2(qi0, __float_as_uint(qd0));
+                ovf_n += __popcll(sm0);
+              }
+            }
+          }
+          if (first_pass) {  // every entering key lands behind the last chunk: nothing moved, ranks still needed
             uint64_t rem = im;
             while (rem) {
-              int j = __builtin_ctzll(rem);
+              const int j = __builtin_ctzll(rem);
               rem &= rem - 1;
               rank += (rl64(key, j) < key) ? 1u : 0u;
             }
           }
           if (ins) newpos = pos + rank;
-          // Shift the queue in place, TOP chunk first: an entry moves up by the number of entering keys
-          // below it, i.e. into its own chunk or the one above -- both already read.  One chunk of the
-          // queue is in registers at a time (a wave's LDS reads and writes execute in program order).
-          // What falls past `ef` is spilled.
-          for (int c = (int)((qlen - 1u) >> 6); c >= (int)c_first; c--) {
-            const uint32_t i = lane + 64u * c;
-            const bool has = i < qlen;
-            const uint32_t qi = has ? Qid[i] : PH_EMPTY32;
-            const float qd = has ? Qd[i] : PH_FMAX;
-            const uint64_t qk = has ? mkkey(qd, qi) : KEY_NONE;
-            uint32_t sh = 0;
-            uint64_t rem = im;
-            while (rem) {
-              int j = __builtin_ctzll(rem);
-              rem &= rem - 1;
-              sh += (rl64(key, j) < qk) ? 1u : 0u;
-            }
-            const uint32_t np = i + sh;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the chunk is in registers before it is overwritten
-            if (has && np < ef) {
-              Qid[np] = qi;
-              Qd[np] = qd;
-            }
-            const bool spill = has && np >= ef;
-            const uint64_t sm = __ballot(spill);
-            if (sm) {
-              uint32_t at = ovf_n + __popcll(sm & lt);
-              if (spill && at < a.ovf_cap) ovf[at] = make_uint2(qi, __float_as_uint(qd));
-              ovf_n += __popcll(sm);
-            }
-          }
           __syncthreads();
+          PH_TICK(6)
         }
         {
           if (fresh && newpos < ef) {
@@ -413,6 +473,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         qlen = min(ef, qlen + m);
         scan_from = min(pop >= 0 ? (uint32_t)pop + 1u : scan_from, pos_min);
         __syncthreads();
+        PH_TICK(4)
         if (ovf_n > a.ovf_cap) {
           err = ST_OVERFLOW;
           break;
@@ -423,6 +484,12 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
       }
       if (err != ST_OK) break;
+#ifdef PH_HOP_PROFILE
+      if (lane == 0 && q == 0)
+        printf("hop profile q0 layer %u%s: hops %u evals %u | us: pop %.1f nbr %.1f visited %.1f dist %.1f merge %.1f (+ search/rank %.1f, shift %.1f)\n", li,
+               tl ? " (dense)" : "", n_hops - hops_before, n_dist - dist_before, tprof[0] * 0.01, tprof[1] * 0.01, tprof[2] * 0.01,
+               tprof[3] * 0.01, tprof[4] * 0.01, tprof[5] * 0.01, tprof[6] * 0.01);
+#endif
 
       // ---- clear this layer's visited bits (queue + spill hold every evaluated node)
       if (tl) {
@@ -611,12 +678,12 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   ph_search_body<CAPC, Dist>(a);
 }
 
-// Small batches leave most of the chip idle and finish with their slowest query: their kernels keep 12 rows in
-// flight per wave (one load round per hop instead of four) at one or two waves per SIMD.  Same arithmetic per
-// row, so the same results.
+// Small batches leave most of the chip idle and finish with their slowest query: their kernels keep up to 24
+// rows in flight per wave (one load round per hop instead of up to twelve) at one wave per SIMD.  Same
+// arithmetic per row, so the same results.
 template <int CAPC, int NV>
 __global__ __launch_bounds__(64, 1) void ph_search_kernel_lat(PhSearchArgs a) {
-  ph_search_body<CAPC, DistF32<NV, 12>>(a);
+  ph_search_body<CAPC, DistF32<NV, 0>>(a);
 }
 
 // the register-table policy keeps a whole lookup table in VGPRs: two waves per SIMD is its register budget
