@@ -370,21 +370,20 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         bool did = im != 0;
         if (!im && m >= 2) did = __ballot(fresh && myd == dtail) != 0;
         if (im) {
-          pos = lds_lower_bound(Qid, Qd, qlen, key);  // every lane searches (uniform trip count); only `ins` lanes use it
-          // queue entries below the smallest insertion point stay where they are: their chunks are
-          // neither read nor rewritten
-          pos_min = wave_min_u32(ins ? pos : 0xFFFFFFFFu);
-          const int c_first = (int)(pos_min >> 6);
-          PH_TICK(5)
-          // Shift the queue in place, TOP chunks first and two 64-entry chunks per pass: an entry moves up by the
-          // number of entering keys below it, i.e. into its own chunk or the one above -- both already in
-          // registers or already rewritten (a wave's LDS reads and writes execute in program order).  One loop over
-          // the entering keys serves both chunks and, in the first pass, the rank of each entering key among the
-          // entering keys.  What falls past `ef` is spilled.
-          uint32_t rank = 0;
+          // One pass handles two 64-entry chunks of the queue, TOP chunks first.  For every entering key k_j (a
+          // scalar loop over the bits of `im`) the pass counts, per queue slot, the entering keys below it (the
+          // distance the slot's entry moves up: into its own chunk or the one above, both already in registers
+          // or already rewritten -- a wave's LDS reads and writes execute in program order) and, per entering
+          // key, the processed slots holding a greater key (s_bcnt1 of the same compare mask), which gives its
+          // insertion point without a search.  The first pass also ranks the entering keys among themselves.
+          // The passes stop at the first chunk whose head is below every entering key: everything under it
+          // stays where it is and is neither read nor rewritten.  What falls past `ef` is spilled.
+          uint32_t rank = 0, greater = 0;
           bool first_pass = true;
-          for (int c = (int)((qlen - 1u) >> 6); c >= c_first; c -= 2) {
-            const bool two = c > c_first;  // chunk c-1 belongs to this pass (it is a full chunk)
+          const int c_top = (int)((qlen - 1u) >> 6);
+          int c = c_top, c_low;
+          for (;;) {
+            const bool two = c > 0;  // chunk c-1 belongs to this pass (it is a full chunk)
             const uint32_t i1 = lane + 64u * (uint32_t)c, i0 = i1 - 64u;
             const bool has1 = i1 < qlen;
             const uint32_t qi1 = has1 ? Qid[i1] : PH_EMPTY32;
@@ -405,8 +404,11 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
                 rem &= rem - 1;
                 const uint64_t kj = rl64(key, j);
                 rank += (kj < key) ? 1u : 0u;
-                sh1 += (kj < qk1) ? 1u : 0u;
-                sh0 += (kj < qk0) ? 1u : 0u;
+                const bool g1 = kj < qk1, g0 = two && kj < qk0;
+                sh1 += g1 ? 1u : 0u;
+                sh0 += g0 ? 1u : 0u;
+                const uint32_t g = (uint32_t)__popcll(__ballot(g1)) + (uint32_t)__popcll(__ballot(g0));
+                greater += lane == (uint32_t)j ? g : 0u;
               }
               first_pass = false;
             } else {
@@ -414,8 +416,11 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
                 const int j = __builtin_ctzll(rem);
                 rem &= rem - 1;
                 const uint64_t kj = rl64(key, j);
-                sh1 += (kj < qk1) ? 1u : 0u;
-                sh0 += (kj < qk0) ? 1u : 0u;
+                const bool g1 = kj < qk1, g0 = two && kj < qk0;
+                sh1 += g1 ? 1u : 0u;
+                sh0 += g0 ? 1u : 0u;
+                const uint32_t g = (uint32_t)__popcll(__ballot(g1)) + (uint32_t)__popcll(__ballot(g0));
+                greater += lane == (uint32_t)j ? g : 0u;
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // both chunks are in registers before either is overwritten
@@ -444,16 +449,16 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
                 ovf_n += __popcll(sm0);
               }
             }
+            c_low = two ? c - 1 : c;
+            // the head of the lowest chunk done (its lane 0) is below every entering key: so is all the rest
+            if (c_low == 0 || rl32(two ? sh0 : sh1, 0) == 0u) break;
+            c -= 2;
           }
-          if (first_pass) {  // every entering key lands behind the last chunk: nothing moved, ranks still needed
-            uint64_t rem = im;
-            while (rem) {
-              const int j = __builtin_ctzll(rem);
-              rem &= rem - 1;
-              rank += (rl64(key, j) < key) ? 1u : 0u;
-            }
-          }
+          // slots of the chunks done (the empty ones of the top chunk count as greater) + all of the chunks below
+          pos = 64u * (uint32_t)(c_top + 1) - greater;
           if (ins) newpos = pos + rank;
+          pos_min = rl32(pos, __builtin_ctzll(__ballot(ins && rank == 0u)));  // the smallest entering key's
+          PH_TICK(5)
           __syncthreads();
           PH_TICK(6)
         }
