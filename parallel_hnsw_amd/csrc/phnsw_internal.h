@@ -119,6 +119,8 @@ struct PhWorkspace {
   size_t tiny_nbr_bytes = 0;
   uint32_t *tiny_member = nullptr;
   size_t tiny_member_bytes = 0;
+  float4 *tiny_pq = nullptr, *tiny_pn = nullptr;  // matrix-core operands: packed positions / nodes (tiny.hip)
+  size_t tiny_pq_bytes = 0, tiny_pn_bytes = 0;
   // per-dispatch bookkeeping of the last descent (phnsw_last_search_dispatches): evd[0] closes the
   // dense-top-layer kernels, evd[1 + i] search launch i; dtotals[i] = {distance evaluations, hops}
   hipEvent_t evd[PH_MAX_DISPATCH + 1] = {};

@@ -21,9 +21,13 @@
 //                          sorted, lib.rs:685 / search.rs:150-157, so NodeId order == table-id
 //                          order and queue ties break identically), plus a membership mask.
 //
+//   ph_tiny_table_mfma_kernel  the same table on the matrix cores for dot-product metrics over rows of whole
+//                          64-chunk groups (256 / 768 / 1536 floats): chains of v_mfma_f32_32x32x1_2b_f32, one
+//                          fused multiply-add per K step, visited in the butterfly's own tree order -- the same
+//                          bits again (see the comment above the kernel).
+//
 // search.hip then walks those layers with its visited set and its table row in LDS and never
-// touches a vector row there.  VALU bound, not HBM: 2*dim flop per entry at the f32 vector rate.
-// MFMA would change the summation order (k-ordered chain), i.e. the result bits: not used.
+// touches a vector row there.  Compute bound, not HBM: 2*dim flop per entry at the f32 vector or matrix rate.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -227,27 +231,195 @@ __global__ __launch_bounds__(256) void ph_tiny_table_kernel(PhTinyTableArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ the same table on the matrix cores
+//
+// D[position][node] is a GEMM, but its bits are fixed by the per-hop evaluation: lane l of a wave chains
+// fma(x, q, acc) over the 4 components of float4 chunks l, l + 64, ... (chain_partial) and the 64 partial sums
+// meet in the xor-butterfly's tree (32, 16, 8, 4, 2, 1).  v_mfma_f32_32x32x1_2b_f32 performs exactly one fused
+// multiply-add per output element and K step (measured bit-identical to v_fma_f32 including denormals:
+// scripts/micro/mfma_fma_exact.hip), so a chain of NV*4 such instructions over the columns of lane l builds
+// p_l for 32 x 32 (position, node) pairs at once -- its two blocks take lanes l and l + 32, whose sum is the
+// butterfly's first step.  The 32 sums s1[l] are visited in bit-reversed order, which is a depth-first walk of
+// the butterfly's tree: finished subtrees are added as soon as both halves exist, five pending 32 x 32 tiles at
+// most.  Operands are packed once per launch (ph_tiny_pack_kernel) so that what a leaf needs of 32 rows is one
+// contiguous, lane-ordered run: [row tile][leaf t][chunk k][block b][row x] float4.
+typedef float ph_f32x32 __attribute__((ext_vector_type(32)));
+
+__host__ __device__ constexpr uint32_t ph_rev5(uint32_t t) {
+  return ((t & 1u) << 4) | ((t & 2u) << 2) | (t & 4u) | ((t & 8u) >> 2) | ((t & 16u) >> 4);
+}
+
+struct PhTinyPackArgs {
+  const float *vecs;     // stored rows
+  uint32_t ld;
+  const float *queries;  // raw query rows, or nullptr: rows are stored vectors
+  uint32_t ldq;
+  const uint32_t *ids;    // row -> VectorId of a stored vector (when queries == nullptr)
+  const uint32_t *order;  // nullable: row r reads entry order[r]
+  uint32_t n, n_pad;      // rows, rows rounded up to the block tile (the rest is zero)
+  uint32_t nv;            // float4 chunks per lane
+  float4 *out;
+};
+
+// blockDim (32 rows, 8 chunks): a row's 8 chunks are one 128-byte read, a chunk's 32 rows one 512-byte write
+__global__ void ph_tiny_pack_kernel(PhTinyPackArgs p) {
+  const uint32_t r = blockIdx.x * 32u + threadIdx.x;
+  const uint32_t c = blockIdx.y * 8u + threadIdx.y;  // < 64 * nv
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < p.n) {
+    const uint32_t e = p.order ? p.order[r] : r;
+    const float4 *src = p.queries ? (const float4 *)(p.queries + (uint64_t)e * p.ldq)
+                                  : (const float4 *)(p.vecs + (uint64_t)p.ids[e] * p.ld);
+    v = src[c];
+  }
+  const uint32_t t = ph_rev5(c & 31u), b = (c >> 5) & 1u, k = c >> 6;
+  p.out[(((((uint64_t)(r >> 5) * 32u + t) * p.nv + k) * 2u + b) << 5) + (r & 31u)] = v;
+}
+
+struct PhTinyMfmaArgs {
+  const float4 *pq, *pn;  // packed positions / nodes
+  uint32_t npos, tiny_n, stride;
+  uint32_t qtiles, ntiles;  // 64-row block tiles along each side
+  int metric;
+  float *D;
+};
+
+// 256 threads = 4 waves, block tile 64 positions x 64 nodes, wave w: positions half w & 1, nodes half w >> 1.
+// G leaves of all four 32-row tiles are staged per step (double buffered: the next step's global loads are in
+// flight while the matrix cores work on this one); wave w stages row tile w (0, 1: positions; 2, 3: nodes), G * NV
+// wave-wide loads of 1 KiB per step.  The butterfly's tree is written as a compile-time recursion, so that the
+// pending partial tiles are plain locals (five at most) and every index is a constant.
+template <int NV, int G>
+struct PhMfmaTile {
+  static constexpr int TILE4 = G * NV * 64;  // float4 of one row tile in one step
+  static constexpr int BUF4 = 4 * TILE4;
+  static constexpr int NG = 32 / G;
+  float4 *sm4;
+  const float4 *mysrc;   // this wave's row tile in the packed operand, + lane
+  const float4 *A0, *B0;  // this wave's operand tiles in LDS buffer 0, + lane
+  float4 *mydst;          // where this wave parks its row tile in LDS buffer 0, + lane
+  float4 stage[G * NV];
+
+  __device__ __forceinline__ void fetch(int g) {
+#pragma unroll
+    for (int i = 0; i < G * NV; i++) stage[i] = mysrc[g * TILE4 + i * 64];
+  }
+  __device__ __forceinline__ void park(int buf) {
+#pragma unroll
+    for (int i = 0; i < G * NV; i++) mydst[buf * BUF4 + i * 64] = stage[i];
+  }
+  // s1 of leaf T: p_l + p_(l + 32) for l = ph_rev5(T), 32 x 32 pairs (16 registers per lane)
+  template <int T>
+  __device__ __forceinline__ void leaf(float (&out)[16]) {
+    constexpr int g = T / G, tt = T % G;
+    if (tt == 0 && g + 1 < NG) fetch(g + 1);
+    ph_f32x32 acc;
+#pragma unroll
+    for (int v = 0; v < 32; v++) acc[v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const float4 qa = A0[(g & 1) * BUF4 + (tt * NV + k) * 64];
+      const float4 xb = B0[(g & 1) * BUF4 + (tt * NV + k) * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x1f32(qa.x, xb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x1f32(qa.y, xb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x1f32(qa.z, xb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x1f32(qa.w, xb.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      out[v] = acc[v] + acc[v + 16];
+      // pins the add here: instruction selection otherwise keeps all 32 leaves' accumulators (spilled) and adds at the end
+      asm volatile("" : "+v"(out[v]));
+    }
+    if (tt == G - 1) {
+      if (g + 1 < NG) park((g + 1) & 1);
+      __syncthreads();
+    }
+  }
+  // the subtree of 2^L leaves starting at leaf T0 (bit-reversed leaf order = the butterfly's pairing, deepest first)
+  template <int L, int T0>
+  __device__ __forceinline__ void subtree(float (&out)[16]) {
+    if constexpr (L == 0) {
+      leaf<T0>(out);
+    } else {
+      float lo[16], hi[16];
+      subtree<L - 1, T0>(lo);
+      subtree<L - 1, T0 + (1 << (L - 1))>(hi);
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        out[v] = lo[v] + hi[v];
+        asm volatile("" : "+v"(out[v]));
+      }
+    }
+  }
+};
+
+template <int NV, int G>
+__global__ __launch_bounds__(256) void ph_tiny_table_mfma_kernel(PhTinyMfmaArgs a) {
+  extern __shared__ float4 sm4[];
+  using Tile = PhMfmaTile<NV, G>;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs, so the blocks one L2 sees are B % 8 == xcd;
+  // each XCD walks its own 8 x 8 super-tiles (8 position tiles x 8 node tiles = 3 MiB of operands, inside its L2)
+  const uint32_t B = blockIdx.x, xcd = B & 7u, slot = B >> 3;
+  const uint32_t sq = (a.qtiles + 7u) / 8u;  // super-tiles along positions
+  const uint32_t super = (slot >> 6) * 8u + xcd, within = slot & 63u;
+  const uint32_t qt = (super % sq) * 8u + (within & 7u), nt = (super / sq) * 8u + (within >> 3);
+  if (qt >= a.qtiles || nt >= a.ntiles) return;  // the whole block
+  Tile t;
+  t.sm4 = sm4;
+  t.mysrc = (w < 2u ? a.pq + (uint64_t)(2u * qt + w) * (32u * NV * 64u)
+                    : a.pn + (uint64_t)(2u * nt + (w - 2u)) * (32u * NV * 64u)) + lane;
+  t.mydst = sm4 + w * Tile::TILE4 + lane;
+  t.A0 = sm4 + (w & 1u) * Tile::TILE4 + lane;
+  t.B0 = sm4 + (2u + (w >> 1)) * Tile::TILE4 + lane;
+  t.fetch(0);
+  t.park(0);
+  __syncthreads();
+  float V[16];
+  t.template subtree<5, 0>(V);
+  // 32x32 accumulator layout: register v of lane L holds row 8 * (v / 4) + 4 * (L / 32) + v % 4, column L % 32;
+  // rows are the A operand's (positions), columns the B operand's (nodes): a register is two 128-byte row pieces
+  const uint32_t r = (2u * nt + (w >> 1)) * 32u + (lane & 31u);
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const uint32_t p = (2u * qt + (w & 1u)) * 32u + 8u * (v / 4) + 4u * (lane >> 5) + (v & 3);
+    if (p < a.npos && r < a.tiny_n) a.D[(uint64_t)p * a.stride + r] = finalize_metric(V[v], a.metric);
+  }
+}
+
 // ------------------------------------------------------------------ host side
 
 void ph_tiny_free(PhWorkspace &ws) {
   if (ws.tiny_d) hipFree(ws.tiny_d);
   if (ws.tiny_nbr) hipFree(ws.tiny_nbr);
   if (ws.tiny_member) hipFree(ws.tiny_member);
+  if (ws.tiny_pq) hipFree(ws.tiny_pq);
+  if (ws.tiny_pn) hipFree(ws.tiny_pn);
+  ws.tiny_pq = ws.tiny_pn = nullptr;
+  ws.tiny_pq_bytes = ws.tiny_pn_bytes = 0;
   ws.tiny_d = nullptr;
   ws.tiny_nbr = ws.tiny_member = nullptr;
   ws.tiny_d_bytes = ws.tiny_nbr_bytes = ws.tiny_member_bytes = 0;
 }
 
-// Which leading layers run densely.  Measured at 1M x 768 (100 000 queries): the tile pass costs 0.030 us per
-// (query, node), a table lookup on the walk 0.08 us, a gathered evaluation 0.28-0.35 us; closest_nodes evaluates
-// about 7 x number_of_candidates nodes of a layer it cannot exhaust.  A layer of n nodes is therefore worth a
-// table when n * 0.030 < 7 * ef * 0.2, i.e. n <= 48 * ef (and <= PH_TINY_MAX_NODES): at ef 104 the 7 000-node layer
-// of a 1M index stays on the per-hop path, at ef >= 150 (and in every build round, ef 300) it is tabulated.
-// PHNSW_TINY_MAX overrides.
+// rows the matrix-core table kernel takes: a dot-product metric over whole 64-chunk rows (256 / 768 / 1536 floats)
+static bool tiny_mfma_shape(int metric, uint32_t ld) {
+  return metric != PHNSW_METRIC_L2 && (ld == 256u || ld == 768u || ld == 1536u) && !getenv("PHNSW_TINY_VALU");
+}
+
+// Which leading layers run densely.  Measured at 1M x 768 (100 000 queries): the vector-unit tile pass costs
+// 0.030 us per (query, node), the matrix-core one 0.016 us, a table lookup on the walk 0.08 us, a gathered
+// evaluation 0.28-0.35 us; closest_nodes evaluates about 7 x number_of_candidates nodes of a layer it cannot
+// exhaust.  A layer of n nodes is therefore worth a table when n * cost < 7 * ef * 0.2, i.e. n <= 48 * ef (80 * ef
+// on the matrix cores) and <= PH_TINY_MAX_NODES: at ef 104 the 7 000-node layer of a 1M x 768 cosine index is
+// tabulated on the matrix cores and stays on the per-hop path otherwise; at ef >= 150 (and in every build round,
+// ef 300) it is tabulated either way.  PHNSW_TINY_MAX overrides.
 uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t ef) {
   const bool off = getenv("PHNSW_NO_TINY") != nullptr;  // tests compare both paths
   if (off || !ix->store->rows || ix->store->ld / 4 > 384) return 0;
-  uint64_t cap = std::min<uint64_t>(PH_TINY_MAX_NODES, 48ull * ef);
+  const uint64_t per_ef = tiny_mfma_shape(ix->store->metric, ix->store->ld) ? 80ull : 48ull;
+  uint64_t cap = std::min<uint64_t>(PH_TINY_MAX_NODES, per_ef * ef);
   if (const char *e = getenv("PHNSW_TINY_MAX"))
     if (atoi(e) > 0) cap = std::min<uint64_t>(PH_TINY_MAX_NODES, (uint64_t)atoi(e));
   uint32_t T = 0;
@@ -323,6 +495,60 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
   if (const char *e = getenv("PHNSW_TINY_DBG")) t.dbg = (uint32_t)atoi(e);
   const uint32_t nv4 = a.dist.nv4;
   const int nv = nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : 6);
+  // dot-product metrics over whole 64-chunk rows go to the matrix cores (same bits, see above); the Euclidean
+  // chain (fma(d, d, acc) of a difference) is not a product of the two operands and stays on the vector units, as
+  // do ragged rows and launches of a handful of queries.  PHNSW_TINY_VALU=1 forces the vector kernel (tests).
+  const bool mfma = tiny_mfma_shape(a.dist.metric, nv4 * 4u) && nv4 == 64u * (uint32_t)nv && npos >= 32u;
+  if (mfma) {
+    const uint32_t qtiles = (npos + 63u) / 64u, ntiles = (tn + 63u) / 64u;
+    const size_t row_bytes = (size_t)nv * 64u * sizeof(float4);
+    PH_HIP(grow(&ws.tiny_pq, &ws.tiny_pq_bytes, (size_t)qtiles * 64u * row_bytes));
+    PH_HIP(grow(&ws.tiny_pn, &ws.tiny_pn_bytes, (size_t)ntiles * 64u * row_bytes));
+    PhTinyPackArgs k;
+    memset(&k, 0, sizeof(k));
+    k.vecs = a.dist.vecs;
+    k.ld = a.dist.ld;
+    k.nv = (uint32_t)nv;
+    k.queries = a.queries;
+    k.ldq = a.ldq;
+    k.ids = a.qids;
+    k.order = a.order;
+    k.n = npos;
+    k.n_pad = qtiles * 64u;
+    k.out = ws.tiny_pq;
+    hipLaunchKernelGGL(ph_tiny_pack_kernel, dim3(k.n_pad / 32u, 8u * (uint32_t)nv), dim3(32, 8), 0, stream, k);
+    k.queries = nullptr;
+    k.ids = a.layers[T - 1].nodes;
+    k.order = nullptr;
+    k.n = tn;
+    k.n_pad = ntiles * 64u;
+    k.out = ws.tiny_pn;
+    hipLaunchKernelGGL(ph_tiny_pack_kernel, dim3(k.n_pad / 32u, 8u * (uint32_t)nv), dim3(32, 8), 0, stream, k);
+    PH_HIP(hipGetLastError());
+    PhTinyMfmaArgs m;
+    memset(&m, 0, sizeof(m));
+    m.pq = ws.tiny_pq;
+    m.pn = ws.tiny_pn;
+    m.npos = npos;
+    m.tiny_n = tn;
+    m.stride = stride;
+    m.qtiles = qtiles;
+    m.ntiles = ntiles;
+    m.metric = a.dist.metric;
+    m.D = ws.tiny_d;
+    const uint32_t supers = ((qtiles + 7u) / 8u) * ((ntiles + 7u) / 8u);
+    const uint32_t blocks = (supers + 7u) / 8u * 8u * 64u;
+    constexpr int G = 2;
+    const size_t lds = (size_t)2 * 4 * G * nv * 64 * sizeof(float4);
+    if (nv == 1) {
+      hipLaunchKernelGGL((ph_tiny_table_mfma_kernel<1, G>), dim3(blocks), dim3(256), lds, stream, m);
+    } else if (nv == 3) {
+      hipLaunchKernelGGL((ph_tiny_table_mfma_kernel<3, G>), dim3(blocks), dim3(256), lds, stream, m);
+    } else {
+      PH_HIP(hipFuncSetAttribute((const void *)ph_tiny_table_mfma_kernel<6, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((ph_tiny_table_mfma_kernel<6, G>), dim3(blocks), dim3(256), lds, stream, m);
+    }
+  } else {
   const uint32_t qt = nv == 6 ? 4u : 8u;
   const uint32_t gx = (npos + 4u * qt - 1u) / (4u * qt);
   const uint32_t tiles = (tn + 7u) / 8u;
@@ -336,6 +562,7 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
     hipLaunchKernelGGL((ph_tiny_table_kernel<3, 8>), grid, dim3(256), 0, stream, t);
   else
     hipLaunchKernelGGL((ph_tiny_table_kernel<6, 4>), grid, dim3(256), 0, stream, t);
+  }
   PH_HIP(hipGetLastError());
   a.tiny_layers = T;
   a.tiny_n = tn;

@@ -37,6 +37,7 @@ CASES = [
     (5000, 200, ph.METRIC_L2, (300, 300, 2)),            # L2 chain, queue of 300
     (700, 64, ph.METRIC_COSINE_HALF, (32, 32, 3)),       # every layer is a dense one
     (30000, 128, ph.METRIC_COSINE_HALF, (64, 64, 2)),    # table layer of ~2500 nodes: its rows stay in global memory
+    (8000, 256, ph.METRIC_ONE_MINUS_DOT, (64, 64, 2)),   # one whole chunk per lane: the matrix-core table, 4 steps per leaf
 ]
 
 
