@@ -342,9 +342,19 @@ def worker(args):
             lo, hi = x["layers"]
             e = {"ms": round(float(np.mean(x["ms"])), 4)}
             if i == 0:
-                e["kernel"] = "ph_tiny_prep_kernel + ph_tiny_table_kernel (dense top layers, csrc/tiny.hip)"
-                if e["ms"] < 1e-3 and x["n_dist"] == 0:
+                t_layers, t_nodes, t_mfma = index.dense_top_layers(ef)
+                e["kernel"] = ("ph_tiny_prep_kernel + ph_tiny_pack_kernel + ph_tiny_table_mfma_kernel" if t_mfma else
+                               "ph_tiny_prep_kernel + ph_tiny_table_kernel") + " (dense top layers, csrc/tiny.hip)"
+                if t_layers == 0:
                     e["note"] = "no dense layers in this descent"
+                else:
+                    flop = 2.0 * store.ld * t_nodes * args.nq
+                    peak = 157.3 if t_mfma else 78.6
+                    e.update({"layers": "0-%d" % (t_layers - 1), "table_nodes": t_nodes, "bound": "mfma" if t_mfma else "valu",
+                              "flop": flop, "tflops": round(flop / (e["ms"] * 1e-3) / 1e12, 1), "peak_tflops": peak,
+                              "frac": round(flop / (e["ms"] * 1e-3) / 1e12 / peak, 3),
+                              "note": "distance table of every query x every node of the largest dense layer; f32, the per-hop "
+                                      "path's bits; ms includes the table-id rewrite and operand packing kernels"})
             else:
                 e.update({"kernel": "ph_search_kernel", "layers": "%d-%d" % (lo, hi - 1), "distance_evals": x["n_dist"],
                           "hops": x["n_hops"],
@@ -488,7 +498,7 @@ def worker(args):
             # peak (rows shared through L2 / the dense tables), which is not a roofline fraction
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                          "traffic_source": None,
-                         "kernel": "ph_search_kernel (+ ph_tiny_table_kernel)", "kernel_ms": round(res["kernel_ms"], 4),
+                         "kernel": "ph_search_kernel (+ ph_tiny_table_mfma_kernel)", "kernel_ms": round(res["kernel_ms"], 4),
                          "kernel_ms_note": "HIP events on the launch stream around one isolated launch (all its dispatches), "
                                            "mean of %d launches after the timed region" % min(args.steps, 10),
                          "algorithmic_bytes_per_launch": res["alg_bytes"],

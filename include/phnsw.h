@@ -209,6 +209,12 @@ int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
 int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap, uint32_t *count, float *ms,
                                  uint64_t *n_dist, uint64_t *n_hops, uint32_t *layer_lo,
                                  uint32_t *layer_hi);
+/* how a search with this number_of_candidates treats the leading layers (measurement only): *layers =
+ * how many of them are walked through the dense distance table (csrc/tiny.hip), *nodes = nodes of
+ * the largest of them (the table's width), *matrix_cores = 1 when the table is built by the MFMA
+ * kernel (dot-product metric, rows of 256 / 768 / 1536 floats), 0 for the vector-unit kernel. */
+int phnsw_dense_top_layers(const phnsw_index *ix, uint64_t number_of_candidates, uint32_t *layers,
+                           uint64_t *nodes, uint32_t *matrix_cores);
 
 /* ---- phase API: the per-round pieces of phnsw_generate_layer / phnsw_link_layer /
  * phnsw_stochastic_recall_at over a NODE RANGE, device buffers, u32 ids (0xFFFFFFFF empty).

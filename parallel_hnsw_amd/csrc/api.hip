@@ -854,6 +854,20 @@ extern "C" int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap,
   return 0;
 } catch (...) { return ph_caught(); }
 
+extern "C" int phnsw_dense_top_layers(const phnsw_index *ix, uint64_t number_of_candidates, uint32_t *layers, uint64_t *nodes,
+                                      uint32_t *matrix_cores) try {
+  if (!ix || !ix->store) {
+    ph_set_error("phnsw_dense_top_layers: null index");
+    return PHNSW_E_INVALID;
+  }
+  const uint32_t ef = (uint32_t)std::min<uint64_t>(number_of_candidates, 0xFFFFFFFFull);
+  const uint32_t T = ph_tiny_layer_count(ix, (uint32_t)ix->layers.size(), ef);
+  if (layers) *layers = T;
+  if (nodes) *nodes = T ? ix->layers[T - 1].n_nodes : 0;
+  if (matrix_cores) *matrix_cores = (T && ph_tiny_matrix_cores(ix)) ? 1u : 0u;
+  return 0;
+} catch (...) { return ph_caught(); }
+
 // host-pointer search: stage, launch, grow the spill workspace and retry the few queries
 // that overflowed it, convert u32 -> u64 ids
 static int search_host(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,

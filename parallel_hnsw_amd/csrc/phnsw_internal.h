@@ -237,6 +237,7 @@ int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const u
 // [0, npos) (position p = query order[p], or p itself) on `stream`.  a.tiny_layers = 0 when unused.
 int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uint32_t max_layers, hipStream_t stream);
 size_t ph_tiny_lds_bytes(const PhSearchArgs &a);
+bool ph_tiny_matrix_cores(const phnsw_index *ix);  // the table of this index's store is built by the MFMA kernel
 uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t ef);  // leading layers a launch may run densely
 uint64_t ph_tiny_max_positions(const phnsw_index *ix, uint32_t n_layers, uint32_t ef);  // 0 = no dense layers for this launch shape
 void ph_tiny_free(PhWorkspace &ws);

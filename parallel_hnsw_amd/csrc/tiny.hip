@@ -408,6 +408,8 @@ static bool tiny_mfma_shape(int metric, uint32_t ld) {
   return metric != PHNSW_METRIC_L2 && (ld == 256u || ld == 768u || ld == 1536u) && !getenv("PHNSW_TINY_VALU");
 }
 
+bool ph_tiny_matrix_cores(const phnsw_index *ix) { return tiny_mfma_shape(ix->store->metric, ix->store->ld); }
+
 // Which leading layers run densely.  Measured at 1M x 768 (100 000 queries): the vector-unit tile pass costs
 // 0.030 us per (query, node), the matrix-core one 0.016 us, a table lookup on the walk 0.08 us, a gathered
 // evaluation 0.28-0.35 us; closest_nodes evaluates about 7 x number_of_candidates nodes of a layer it cannot

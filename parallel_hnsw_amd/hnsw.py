@@ -597,6 +597,12 @@ class Hnsw:
         return [{"layers": (int(lo[i]), int(hi[i])), "ms": float(ms[i]), "n_dist": int(nd[i]), "n_hops": int(nh[i])}
                 for i in range(min(cap, cnt.value))]
 
+    def dense_top_layers(self, number_of_candidates):
+        """(layers walked through the dense distance table, nodes of the largest, built on the matrix cores?)"""
+        t, n, m = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        check(lib().phnsw_dense_top_layers(self._h, int(number_of_candidates), C.byref(t), C.byref(n), C.byref(m)))
+        return int(t.value), int(n.value), bool(m.value)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

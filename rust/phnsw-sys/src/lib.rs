@@ -142,6 +142,8 @@ extern "C" {
     pub fn phnsw_last_search_dispatches(ix: *const phnsw_index, cap: u32, count: *mut u32, ms: *mut c_float,
                                         n_dist: *mut u64, n_hops: *mut u64, layer_lo: *mut u32,
                                         layer_hi: *mut u32) -> c_int;
+    pub fn phnsw_dense_top_layers(ix: *const phnsw_index, number_of_candidates: u64, layers: *mut u32, nodes: *mut u64,
+                                  matrix_cores: *mut u32) -> c_int;
 
     // ---- phase API (multi-GPU drivers)
     pub fn phnsw_index_create(s: *mut phnsw_store, bp: *const phnsw_build_params, out: *mut *mut phnsw_index) -> c_int;

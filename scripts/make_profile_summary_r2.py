@@ -3,7 +3,8 @@
   <dir>/bench_trace.json                              the JSON line that worker printed
   <dir>/bench_full.json                               the JSON line of the plain `python bench.py` run (with PMC)
 The worker's last `isolated` launches (one per HIP-event reading) are the unit; a launch of the headline batch is
-ph_tiny_prep_kernel + ph_tiny_table_kernel + ph_search_kernel."""
+ph_tiny_prep_kernel + 2 x ph_tiny_pack_kernel + ph_tiny_table_mfma_kernel + ph_search_kernel (or prep + ph_tiny_table_kernel +
+search when the store is not one the matrix-core table takes)."""
 import csv, glob, json, os, sys
 
 d, out_dir = sys.argv[1], sys.argv[2]
@@ -33,25 +34,35 @@ for r in ours:
 if cur:
     launches.append(cur)
 nq = trace["queries_per_step_per_gpu"]
-head = [L for L in launches if len(L) == 3 and "ph_search_kernel" in L[2]["Kernel_Name"]]
+head = [L for L in launches if len(L) in (3, 5) and "ph_search_kernel" in L[-1]["Kernel_Name"]]
 # the timed steps + isolated launches of the headline share one shape; take the `isolated` ones that follow the timed region
 steps = trace["steps"] + trace["warmup"]
 sel = head[-(isolated + 200):]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 by_grid = {}
 for L in head:
-    by_grid.setdefault(L[2].get("Grid_Size", L[2].get("Grid_Size_X", "")), []).append(L)
+    by_grid.setdefault(L[-1].get("Grid_Size", L[-1].get("Grid_Size_X", "")), []).append(L)
 main = max(by_grid.values(), key=len)  # the headline shape is the most frequent one (sweep cells use 8192 queries)
-main = [L for L in main if abs(dur(L[2]) - sorted(dur(x[2]) for x in main)[len(main) // 2]) / dur(L[2]) < 0.25]
+main = [L for L in main if abs(dur(L[-1]) - sorted(dur(x[-1]) for x in main)[len(main) // 2]) / dur(L[-1]) < 0.25]
 last = main[-isolated:]
+
+
+def short(r):
+    n = r["Kernel_Name"]
+    for k in ("ph_tiny_prep_kernel", "ph_tiny_pack_kernel", "ph_tiny_table_mfma_kernel", "ph_tiny_table_kernel", "ph_search_kernel"):
+        if k in n:
+            return k
+    return n
+
+
 summary = {
     "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --role worker " + trace.get("argv", ""),
-    "launch": "ph_tiny_prep_kernel + ph_tiny_table_kernel + ph_search_kernel (one isolated launch of the %d-query headline batch)" % nq,
+    "launch": " + ".join(short(r) for r in last[-1]) + " (one isolated launch of the %d-query headline batch)" % nq,
     "launches_averaged": len(last),
-    "avg_ms_per_dispatch": {k: sum(dur(L[i]) for L in last) / len(last) for i, k in enumerate(["ph_tiny_prep_kernel", "ph_tiny_table_kernel", "ph_search_kernel"])},
+    "avg_ms_per_dispatch": {k: sum(dur(r) for L in last for r in L if short(r) == k) / len(last) for k in dict.fromkeys(short(r) for r in last[-1])},
     "avg_ms_sum_of_dispatches": sum(sum(dur(r) for r in L) for L in last) / len(last),
     "avg_ms_first_start_to_last_end": sum((int(L[-1]["End_Timestamp"]) - int(L[0]["Start_Timestamp"])) / 1e6 for L in last) / len(last),
-    "search_kernel_name": last[-1][2]["Kernel_Name"],
+    "search_kernel_name": last[-1][-1]["Kernel_Name"],
     "bench_reported_kernel_ms_same_process": trace["roofline"]["kernel_ms"],
     "bench_reported_dispatches_same_process": trace["roofline"]["dispatches"],
     "bench_value_same_process": trace["value"],

@@ -124,3 +124,35 @@ def test_latency_kernels_equal_throughput_kernels():
         finally:
             del os.environ["PHNSW_NO_LAT"]
         same(lat, thr)
+
+
+def test_mfma_chain_is_an_fma_chain(tmp_path):
+    """the premise of the matrix-core table kernel (csrc/tiny.hip): K = 1 MFMA steps are single fused multiply-adds,
+    bit-identical to v_fma_f32 on unit-range, denormal and wide-exponent operands (scripts/micro/mfma_fma_exact.hip)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "micro", "mfma_fma_exact.hip")
+    exe = str(tmp_path / "mfma_fma_exact")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-w", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "MFMA chain == FMA chain on every trial" in out.stdout, out.stdout
+
+
+def test_matrix_core_table_equals_vector_unit_table():
+    """same launch, both table kernels (PHNSW_TINY_VALU=1 forces the vector-unit one): identical results, including
+    partial 64 x 64 tiles on both sides (333 queries, table layers that are not multiples of 64)"""
+    n, dim = 9000, 768
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters(seed=11, max_link_rounds=1))
+    q = oracle.synth_rows(2 ** 32, 333, dim)[:, :dim]
+    sp = ph.SearchParameters(128, 128, 4)
+    a = h.search_batch(queries=q, sp=sp, stats=True)
+    os.environ["PHNSW_TINY_VALU"] = "1"
+    try:
+        b = h.search_batch(queries=q, sp=sp, stats=True)
+    finally:
+        del os.environ["PHNSW_TINY_VALU"]
+    same(a, b)
