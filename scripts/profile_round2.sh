@@ -20,6 +20,6 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pq_b -o b -- python3 $ROOT/scripts/probe_one.py pq 448 8 > $OUT/pq_b.log 2>&1
 python3 $ROOT/scripts/pmc_kernel.py $OUT/pq_a ph_search_kernel 2 > $OUT/summary/pq_counters.txt
 python3 $ROOT/scripts/pmc_kernel.py $OUT/pq_b ph_search_kernel 2 >> $OUT/summary/pq_counters.txt
-tail -1 $OUT/pq_a.log >> $OUT/summary/pq_counters.txt
+grep "^pq " $OUT/pq_a.log >> $OUT/summary/pq_counters.txt
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 cat $OUT/summary/pq_counters.txt
