@@ -697,6 +697,32 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
       rc = ph_layer_anchor_pos(ix->store, mix->layers[l - 1]);  // first use on a loaded index; no-op afterwards
     if (rc) return rc;
   }
+#ifdef PH_CELL_PROBE
+  {
+    static unsigned long long *probe_dev = nullptr;
+    if (!probe_dev) {
+      PH_HIP(hipMalloc(&probe_dev, 12 * sizeof(unsigned long long)));
+      PH_HIP(hipMemset(probe_dev, 0, 12 * sizeof(unsigned long long)));
+    } else {
+      unsigned long long h[12];
+      PH_HIP(hipDeviceSynchronize());
+      PH_HIP(hipMemcpy(h, probe_dev, sizeof(h), hipMemcpyDeviceToHost));
+      if (h[11]) {
+        fprintf(stderr, "[cell probe] %llu queries, %llu bottom-layer evaluations; within r chain ranks of the landing cell:", h[11], h[10]);
+        for (int k = 0; k < 10; k++) fprintf(stderr, " r<=%u: %.3f", k ? (1u << (k - 1)) : 0u, (double)h[k] / (double)h[10]);
+        fprintf(stderr, "\n");
+      }
+      PH_HIP(hipMemset(probe_dev, 0, 12 * sizeof(unsigned long long)));
+    }
+    a.probe_out = probe_dev;
+    a.probe_pos = nullptr;
+    if (!knn_mode && ix->store->rows && nq >= 1000) {
+      rc = ph_layer_anchor_pos(ix->store, mix->layers[a.n_layers - 1]);
+      if (rc) return rc;
+      a.probe_pos = ix->layers[a.n_layers - 1].pos;
+    }
+  }
+#endif
   rc = ph_search_begin(ws, stream);
   if (rc) return rc;
   // The dense top layers (tiny.hip) keep one table row per launch position; a query list longer

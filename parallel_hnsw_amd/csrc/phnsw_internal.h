@@ -183,6 +183,11 @@ struct PhSearchArgs {
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip
   uint32_t *out_key;            // nullable: locality key of each query after layer_hi - 1
   const uint32_t *key_pos;      // nullable: pos[] of layer layer_hi - 1
+#ifdef PH_CELL_PROBE
+  // experiment: how far, in cell-chain ranks, the bottom layer's evaluations stray from where the query landed
+  const uint32_t *probe_pos;
+  unsigned long long *probe_out;  // [12]: evaluations within 0,1,2,4,...,256 ranks; [10] all; [11] queries
+#endif
   const uint32_t *order;  // nullable: processing order (a permutation of 0..nq-1), see search.hip
   uint32_t seg;           // order != nullptr: positions per XCD segment
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)

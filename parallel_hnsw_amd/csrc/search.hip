@@ -254,6 +254,11 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       // every queue entry below scan_from has been expanded: the pop scan starts at its 64-entry chunk,
       // and a hop's merge touches only the chunks from its first insertion point on
       uint32_t scan_from = 0;
+#ifdef PH_CELL_PROBE
+      const bool probing = a.probe_pos && li == last_layer && !tl;
+      uint32_t probe_p0 = 0, probe_cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (probing) probe_p0 = a.probe_pos[Qid[0] & IDM];
+#endif
 #ifdef PH_HOP_PROFILE
       uint64_t tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       uint64_t t_last = wall_clock64();
@@ -330,6 +335,18 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         const uint64_t fm = __ballot(fresh);
         const uint32_t m = __popcll(fm);
         n_dist += m;
+#ifdef PH_CELL_PROBE
+        if (probing) {
+          uint32_t dd = 0xFFFFFFFFu;
+          if (fresh) {
+            const int d0 = (int)a.probe_pos[nb] - (int)probe_p0;
+            dd = (uint32_t)(d0 < 0 ? -d0 : d0);
+          }
+#pragma unroll
+          for (int k = 0; k < 10; k++) probe_cnt[k] += __popcll(__ballot(fresh && dd <= (k ? (1u << (k - 1)) : 0u)));
+          probe_cnt[10] += m;
+        }
+#endif
         PH_TICK(2)
 
         // distance batch: compare_vec(v, Stored(get_vector(n)))  lib.rs:200-202 -- in a dense top
@@ -489,6 +506,12 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
       }
       if (err != ST_OK) break;
+#ifdef PH_CELL_PROBE
+      if (probing && lane == 0) {
+        for (int k = 0; k < 11; k++) atomicAdd(&a.probe_out[k], (unsigned long long)probe_cnt[k]);
+        atomicAdd(&a.probe_out[11], 1ull);
+      }
+#endif
 #ifdef PH_HOP_PROFILE
       if (lane == 0 && q == 0)
         printf("hop profile q0 layer %u%s: hops %u evals %u | us: pop %.1f nbr %.1f visited %.1f dist %.1f merge %.1f (+ search/rank %.1f, shift %.1f)\n", li,
