@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--skip-tight", dest="no_tight", action="store_true", help="skip round 1's dataset / batch cells")
     ap.add_argument("--skip-pq", dest="no_pq", action="store_true", help="skip the BASELINE config-5 (PQ) measurement")
     ap.add_argument("--no-pmc", action="store_true", help="driver: skip the rocprofv3 counter passes")
+    ap.add_argument("--skip-sharded-build", dest="no_sharded_build", action="store_true",
+                    help="N > 1: do not measure the sharded index build after the search measurement")
+    ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: watchdog of the sharded build, seconds")
     ap.add_argument("--keep-pmc", default="", help="driver: copy the counter CSVs of the passes into this directory")
     ap.add_argument("--role", default="", choices=["", "driver", "worker", "pmc"])
     ap.add_argument("--dump-index", default="", help="worker: serialise the headline index + parameters here")
@@ -198,43 +201,68 @@ def worker(args):
             return self.ids.view(-1)[: self.q.n * ef].view(self.q.n, ef)
 
     def build(store, kind):
+        """the index the searches run on: built by this rank alone (deterministic, so every rank holds the same
+        graph); with several ranks the SHARDED build is measured afterwards, bounded by a watchdog (sharded_probe)"""
         bp = ph.BuildParameters()
-        mode = "single GPU"
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.time()
-        index, comm = None, None
-        if world > 1:
-            # index construction sharded over the ranks: node ranges per round, RCCL all-gather
-            # of the per-node results (parallel_hnsw_amd/sharded.py)
-            try:
-                eng = ph.GpuEngine(store, bp, device=dev)
-                comm = ph.TorchComm()
-                index = ph.ShardedBuilder(eng, comm).generate(np.arange(store.n, dtype=np.uint64))
-                mode = "sharded x%d, %.0f MB all-gathered per rank in %.0f ms" % (
-                    world, comm.bytes_gathered / 1e6, comm.seconds * 1e3)
-            except Exception as exc:  # keep the search measurement alive; say what happened
-                log("sharded build failed (%r); every rank builds the full index instead" % (exc,))
-                index = None
-        if index is None:
-            if world > 1:
-                mode = "replicated (each rank built the full index)"
-            index = ph.Hnsw.generate(store, np.arange(store.n, dtype=np.uint64), bp)
+        index = ph.Hnsw.generate(store, np.arange(store.n, dtype=np.uint64), bp)
         torch.cuda.synchronize()
+        build_s = time.time() - t0
         if world > 1:
             dist.barrier()
-        build_s = time.time() - t0
-        b_dist, b_hops = index.counters()  # every search of the build rounds (this rank's share when sharded)
+        mode = "single GPU" if world == 1 else "every rank built the full index (search replicas); sharded build: see sharded_build"
+        b_dist, b_hops = index.counters()  # every search of the build rounds
         layers = [index._layer(l).node_count() for l in range(index.layer_count())]
         log("%s: index built in %.1f s (%.0f vectors/s), layers %s" % (kind, build_s, store.n / build_s, layers))
         info = {"build_s": build_s, "build_mode": mode, "layers": layers,
                 "build_self_recall": round(index.stochastic_recall(), 5),  # the reference's own estimator, lib.rs:1463-1499
                 "build_distance_evals": b_dist, "build_hops": b_hops}
-        if comm is not None:
-            info["all_gather"] = {"bytes_per_rank": comm.bytes_gathered, "seconds": round(comm.seconds, 4),
-                                  "collectives": getattr(comm, "calls", None)}
         return index, info
+
+    def sharded_probe(store, index, emit):
+        """index construction sharded over the ranks (node ranges per round, RCCL all-gather of the per-node results:
+        parallel_hnsw_amd/sharded.py), timed, and compared with this rank's own build.  The RCCL path could
+        not be exercised on the one-GPU development boxes, so it runs AFTER the search measurement and under a
+        watchdog: if it does not finish in --sharded-timeout seconds, rank 0 prints the line without it and every rank
+        leaves (a hung collective must not cost the search numbers)."""
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(args.sharded_timeout):
+                if rank == 0:
+                    emit({"error": "sharded build did not finish within %d s; line printed without it" % args.sharded_timeout})
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        out = {}
+        try:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            eng = ph.GpuEngine(store, ph.BuildParameters(), device=dev)
+            comm = ph.TorchComm()
+            sh = ph.ShardedBuilder(eng, comm).generate(np.arange(store.n, dtype=np.uint64))
+            torch.cuda.synchronize()
+            dist.barrier()
+            secs = time.time() - t0
+            same = sh.layer_count() == index.layer_count()
+            for l in range(index.layer_count() if same else 0):
+                a_, b_ = sh._layer(l), index._layer(l)
+                same = same and np.array_equal(a_.nodes, b_.nodes) and np.array_equal(a_.neighbors, b_.neighbors)
+            out = {"ranks": world, "seconds": round(secs, 3), "vectors_per_s": round(store.n / secs, 1),
+                   "identical_to_single_gpu_build": bool(same),
+                   "all_gather": {"bytes_per_rank": comm.bytes_gathered, "seconds": round(comm.seconds, 4),
+                                  "collectives": getattr(comm, "calls", None)}}
+            log("sharded build x%d: %.1f s (%.0f vectors/s), identical to the single-GPU graph: %s" % (world, secs, store.n / secs, same))
+        except Exception as exc:  # say what happened; the search numbers stand
+            out = {"error": repr(exc)}
+            log("sharded build failed: %r" % (exc,))
+        finished.set()
+        return out
 
     def sweep_cells(index, store, q_store, gt_t, grid, nq=None):
         """recall@10 and isolated-launch q/s of each (ef, upper, probe_depth) over q_store"""
@@ -518,7 +546,21 @@ def worker(args):
             # no counter passes under torchrun: rank 0's launch is the headline launch, its bytes are replayed from
             # the committed profile when workload and kernel sources match (labelled REPLAYED), else frac stays null
             finish_roofline(line["roofline"], line)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
+
+    def emit(sharded=None):
+        if line is not None:
+            if sharded is not None:
+                line["sharded_build"] = sharded
+                if "all_gather" in sharded:
+                    line["all_gather"] = sharded["all_gather"]
+            print(json.dumps(line), flush=True)
+
+    if world > 1 and not args.no_sharded_build:
+        emit(sharded_probe(store, index, emit))
+    else:
+        emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -784,7 +826,7 @@ def passthrough(args):
         if k in skip:
             continue
         flag = {"n": "--vectors", "nq": "--queries", "no_iid": "--skip-iid", "no_tight": "--skip-tight",
-                "no_pq": "--skip-pq"}.get(k, "--" + k.replace("_", "-"))
+                "no_pq": "--skip-pq", "no_sharded_build": "--skip-sharded-build"}.get(k, "--" + k.replace("_", "-"))
         if isinstance(v, bool):
             if v:
                 out.append(flag)
