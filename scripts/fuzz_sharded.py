@@ -10,24 +10,29 @@ import parallel_hnsw_amd as ph
 
 
 class EmuEngine:
-    """runs every rank's share of a sharded phase on this GPU; rank 0's buffers get rank 0's share"""
+    """runs every rank's share of a sharded phase on this GPU; rank 0's buffers get rank 0's share, the other
+    ranks' blocks are queued packed the way ShardedBuilder._phase packs them (raw bytes side by side)"""
     def __init__(self, eng, w):
-        self._e, self.w, self.stash, self.hits_rest = eng, w, {}, 0
+        self._e, self.w, self.queue, self.hits_rest, self.shard_min = eng, w, [], 0, 0
 
     def __getattr__(self, name):
         return getattr(self._e, name)
 
     def _run(self, total, outs, call):
-        chunk = outs[0].shape[0]
+        whole = total < self.shard_min  # short lists run whole on every rank, no collective
+        chunk = total if whole else -(-total // self.w)
         call(0, min(chunk, total), outs)
-        rest = [[] for _ in outs]
+        if whole:
+            return
+        blocks = []
         for r in range(1, self.w):
             f = min(total, r * chunk); cnt = min(total, f + chunk) - f
-            o2 = [torch.empty_like(o) for o in outs]
-            call(f, cnt, o2)
-            for i, o in enumerate(o2):
-                rest[i].append(o)
-        self.last = (outs, rest)
+            o2 = [torch.zeros((chunk,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device) for o in outs]
+            if cnt:
+                call(f, cnt, [o[:cnt] for o in o2])
+            cols = [o.reshape(chunk, -1).contiguous().view(torch.uint8) for o in o2]
+            blocks.append(cols[0] if len(cols) == 1 else torch.cat(cols, dim=1))
+        self.queue.append(blocks)
 
     def layer_begin(self, vids, W):
         self.n_layer = len(vids)
@@ -56,17 +61,12 @@ class EmuEngine:
 
 
 class EmuComm:
+    """no all_gather_async: the driver then runs a phase as one piece (the pipeline itself is unit-tested on CPU)"""
     def __init__(self, eng, w):
         self.e, self.world, self.rank = eng, w, 0
 
     def all_gather(self, t):
-        outs, rest = self.e.last
-        # packed form: t is the int32 concatenation of rank 0's arrays -> the others' are built the same way
-        blocks = [t]
-        for r in range(self.world - 1):
-            parts = [rest[i][r].view(torch.int32).reshape(rest[i][r].shape[0], -1) for i in range(len(outs))]
-            blocks.append(torch.cat(parts, dim=1) if t.dim() == 2 and t.shape[1] == sum(p.shape[1] for p in parts) else rest[0][r])
-        return torch.cat(blocks, 0)
+        return torch.cat([t] + self.e.queue.pop(0), 0)
 
     def all_reduce_sum(self, values, device):
         return [values[0] + self.e.hits_rest]
