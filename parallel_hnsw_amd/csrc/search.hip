@@ -11,13 +11,17 @@
 //  * a wave owns a query for its whole descent; waves pull queries from one atomic counter
 //    (persistent grid, no tail of idle CUs);
 //  * the query vector lives in registers (NV float4 per lane); a candidate row is read as
-//    NV fully coalesced 1 KiB wave-loads (global_load_dwordx4), 4 rows in flight per wave,
-//    fma-accumulated per lane and reduced with an xor butterfly -- this fixed order is the
-//    oracle's ORC_SUM_BLOCKED64, so results are bit-comparable;
+//    NV fully coalesced 1 KiB wave-loads (global_load_dwordx4), 4 rows in flight per wave
+//    (4 / 12 / 24 in the small-batch kernels), fma-accumulated per lane and reduced with an xor
+//    butterfly -- this fixed order is the oracle's ORC_SUM_BLOCKED64, so results are bit-comparable;
+//  * the small top layers are not gathered at all: their distances come from a table built per
+//    launch on the matrix cores (tiny.hip) and the walk there runs in table ids, visited set in LDS;
 //  * the result queue (PriorityQueue, cap = number_of_candidates) is a sorted (d,id) array
-//    in LDS; a hop's <=64 new candidates are ranked against each other with v_readlane and
-//    against the queue by binary search, then everything moves to its final slot in one
-//    parallel pass (no per-element shifting);
+//    in LDS; a hop's <=64 new candidates are compared with the queue two 64-entry chunks at a
+//    time, top chunks first: one scalar loop over the entering keys (v_readlane + 64-bit compare)
+//    yields every queue slot's shift, every entering key's insertion point (s_bcnt1 of the same
+//    masks -- no search of the queue) and the entering keys' ranks among themselves; then
+//    everything moves to its final slot in place (no per-element shifting);
 //  * the reference's unbounded `visit_queue` (every evaluated node, re-sorted each hop,
 //    pop = smallest (d,id)) is represented exactly as: an "expanded" bit on queue entries
 //    + an append-only spill list in HBM for entries that fell out of / never entered the
