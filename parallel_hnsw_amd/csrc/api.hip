@@ -763,14 +763,28 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
       ws.d_hi[0] = b.n_layers;
       continue;
     }
+    // In a split descent the dense top layers are walked by a launch of their own (ph_search_kernel_dense: twice the
+    // resident waves; 17.3 -> 10.7 ms per 100 000 queries); the layers below follow in the full kernel.  Whether the
+    // table is usable is a device-side flag: if not, the dense launch does nothing and the follow-up starts from
+    // layer 0 (search.hip).  A descent that runs as ONE launch keeps its dense layers there: their walk (latency
+    // bound, no HBM traffic) overlaps other queries' gathers, and taking it out costs more than it saves (measured:
+    // 11.76 -> 12.53 ms per 10 000 queries).
+    const uint32_t Td = b.tiny_layers;
+    const bool dense_first = Td && Td < b.n_layers && b.nq >= PH_DENSE_SPLIT_MIN && !getenv("PHNSW_NO_DENSE_SPLIT");
+    if (dense_first) b.dense_flag = ws.tiny_member + b.tiny_n;
     uint32_t di = 0;
     uint32_t *const out_hit_final = b.out_hit;
-    for (uint32_t lo = 0, hi = first_big; lo < b.n_layers; lo = hi, hi = hi + 1) {
+    const uint32_t first_hi = dense_first ? Td : first_big;
+    for (uint32_t lo = 0, hi = first_hi; lo < b.n_layers; lo = hi, hi = (lo == Td && dense_first && first_big > Td) ? first_big : hi + 1) {
       PhSearchArgs p = b;
       const bool last = hi == b.n_layers;
       p.layer_lo = lo;
       p.layer_hi = hi;
       if (lo) p.tiny_layers = 0;
+      if (dense_first) {
+        p.dense_only = lo == 0 ? 1u : 0u;
+        p.after_dense = lo == Td ? Td : 0u;
+      }
       p.order = lo ? ws.oorder : nullptr;
       p.out_hit = last ? out_hit_final : nullptr;
       p.out_key = last ? nullptr : ws.okey;

@@ -310,6 +310,23 @@ __device__ __forceinline__ float batch_distances(const float *__restrict__ vecs,
 //   DistPQ:      product-quantised store: a per-query table T[m][ksub] in LDS
 //                (T[j][k] = <q_sub_j, c_jk> or |q_sub_j - c_jk|^2), candidates = u8 code
 //                rows, one LANE per candidate, distance = sum_j T[j][code_j] added in j order.
+// DistNone: the policy of a launch that walks dense top layers only (every distance comes from the table)
+struct DistNone {
+  static constexpr bool GLOBAL_TABLE = false;
+  static constexpr bool EARLY = false;
+  __device__ __forceinline__ void prepare_raw(const PhDistArgs &, const float *, float *, uint32_t) {}
+  __device__ __forceinline__ void prepare_stored(const PhDistArgs &, uint32_t, float *, uint32_t) {}
+  __device__ __forceinline__ float batch(const PhDistArgs &, uint64_t, uint32_t, uint32_t) const { return 0.f; }
+};
+template <class D>
+struct dist_is_none {
+  static constexpr bool value = false;
+};
+template <>
+struct dist_is_none<DistNone> {
+  static constexpr bool value = true;
+};
+
 template <int NV, int U = 4>
 struct DistF32 {
   static constexpr bool GLOBAL_TABLE = false;

@@ -14,7 +14,8 @@
 #define PH_FMAX 3.4028234663852886e38f
 #define PH_MAX_LAYERS 24
 #define PH_WAVE 64
-#define PH_MAX_DISPATCH 24  // search launches of one descent (<= PH_MAX_LAYERS)
+#define PH_MAX_DISPATCH 24
+#define PH_DENSE_SPLIT_MIN 2048u  // batches from this size on walk their dense top layers in a launch of its own  // search launches of one descent (<= PH_MAX_LAYERS)
 #define PH_TINY_MAX_NODES 8192u      // largest layer evaluated densely (tiny.hip)
 #define PH_TINY_LDS_NODES 1024u      // up to here a query's table row is staged in LDS
 #define PH_TINY_MAX_LAYERS 8
@@ -121,6 +122,8 @@ struct PhWorkspace {
   size_t tiny_member_bytes = 0;
   float4 *tiny_pq = nullptr, *tiny_pn = nullptr;  // matrix-core operands: packed positions / nodes (tiny.hip)
   size_t tiny_pq_bytes = 0, tiny_pn_bytes = 0;
+  uint2 *dense_ovf = nullptr;  // spill lists of the dense-only launch: [its resident waves][table nodes]
+  size_t dense_ovf_bytes = 0;
   // per-dispatch bookkeeping of the last descent (phnsw_last_search_dispatches): evd[0] closes the
   // dense-top-layer kernels, evd[1 + i] search launch i; dtotals[i] = {distance evaluations, hops}
   hipEvent_t evd[PH_MAX_DISPATCH + 1] = {};
@@ -183,6 +186,15 @@ struct PhSearchArgs {
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip
   uint32_t *out_key;            // nullable: locality key of each query after layer_hi - 1
   const uint32_t *key_pos;      // nullable: pos[] of layer layer_hi - 1
+  // A split descent walks its dense top layers in a launch of its own (ph_search_kernel_dense: no row registers, so
+  // twice the resident waves): dense_only marks that launch (layers [0, tiny_layers), spill lists of dense_ovf_cap
+  // entries in dense_ovf); after_dense = T marks the launch that follows it.  Whether the table was usable (layers
+  // nested) is only known on the device (dense_flag[0] == 0): if not, the dense launch does nothing and the
+  // follow-up starts from layer 0 on the per-hop path.
+  uint32_t dense_only, after_dense;
+  const uint32_t *dense_flag;
+  uint2 *dense_ovf;
+  uint32_t dense_ovf_cap;
 #ifdef PH_CELL_PROBE
   // experiment: how far, in cell-chain ranks, the bottom layer's evaluations stray from where the query landed
   const uint32_t *probe_pos;
@@ -226,10 +238,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
 // descent, its queries sorted by the cell they arrive in (PHNSW_SPLIT_BYTES overrides: tuning knob)
 #define PH_SPLIT_BYTES (4ull << 20)
 static inline bool ph_layer_own_launch(uint64_t n_nodes, uint32_t ld) {
-  static const uint64_t limit = [] {
-    const char *e = getenv("PHNSW_SPLIT_BYTES");
-    return (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (uint64_t)PH_SPLIT_BYTES;
-  }();
+  const char *e = getenv("PHNSW_SPLIT_BYTES");  // read per call: the tests switch it
+  const uint64_t limit = (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (uint64_t)PH_SPLIT_BYTES;
   return n_nodes * (uint64_t)ld * 4u > limit;
 }
 int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip

@@ -76,8 +76,14 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
 
   const uint32_t lane = threadIdx.x;
   const uint64_t lt = lanemask_lt(lane);
+  constexpr bool DENSE_ONLY = dist_is_none<Dist>::value;
+  // the dense-only launch and its follow-up agree through the table's device-side "usable" flag (phnsw_internal.h)
+  const bool table_ok = (a.dense_only || a.after_dense) ? a.dense_flag[0] == 0u : true;
+  if (DENSE_ONLY && !table_ok) return;  // layers not nested: the follow-up launch walks everything per hop
+  const uint32_t layer_lo = a.after_dense ? (table_ok ? a.after_dense : 0u) : a.layer_lo;
   uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
-  uint2 *ovf = a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
+  uint2 *ovf = DENSE_ONLY ? a.dense_ovf + (uint64_t)blockIdx.x * a.dense_ovf_cap : a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
+  const uint32_t ovf_cap = DENSE_ONLY ? a.dense_ovf_cap : a.ovf_cap;
 
   // locality schedule: with an `order` the query list is cut into 8 consecutive segments, one
   // per XCD, so that the queries one L2 serves together are neighbours in `order`; a wave
@@ -122,7 +128,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     // re-ordered by where they landed): layers [layer_lo, layer_hi) of this launch, the running
     // candidates parked in the output rows in between
     const uint32_t layer_hi = a.layer_hi ? a.layer_hi : a.n_layers;
-    if (a.layer_lo && a.status[q] != ST_OK) continue;  // failed in the first launch: keep its status
+    if (layer_lo && a.status[q] != ST_OK) continue;  // failed in the first launch: keep its status
     const uint32_t qnode = a.first_node + q;  // knn modes: the query is a node of the bottom layer
     uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[qnode] : (a.qids ? a.qids[q] : 0u);
     Dist dist;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
 
-    if (a.layer_lo) {
+    if (layer_lo) {
       clen = a.out_len[q];
 #pragma unroll
       for (int c = 0; c < CAPC; c++) {
@@ -155,7 +161,14 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     } else if (!a.knn_mode) {
       // entry_vector + distance_from_entry  search.rs:101-111
       uint32_t entry = a.layers[0].nodes[0];
-      float d0 = dist.batch(a.dist, 1ull, entry, lane);
+      float d0;
+      if constexpr (DENSE_ONLY) {  // the table holds it
+        const PhLayerDev TLy = a.layers[a.tiny_layers - 1];
+        const uint32_t tid = TLy.vec2node ? TLy.vec2node[entry] : entry;
+        d0 = (a.tiny_d + (uint64_t)qpos * a.tiny_stride)[tid < a.tiny_n ? tid : 0u];
+      } else {
+        d0 = dist.batch(a.dist, 1ull, entry, lane);
+      }
       d0 = __uint_as_float(rl32(__float_as_uint(d0), 0));
       n_dist = 1;
       if (lane == 0) {
@@ -172,7 +185,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     }
     __syncthreads();
 
-    for (uint32_t li = a.knn_mode ? last_layer : a.layer_lo; li < layer_hi && err == ST_OK; li++) {
+    for (uint32_t li = a.knn_mode ? last_layer : layer_lo; li < layer_hi && err == ST_OK; li++) {
       PhLayerDev L = a.layers[li];
       // a dense top layer is walked in table ids: ids, id maps and neighbour rows of the table layer
       const bool tl = li < T;
@@ -459,14 +472,14 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               const uint64_t sm1 = __ballot(spill1);
               if (sm1) {
                 const uint32_t at = ovf_n + __popcll(sm1 & lt);
-                if (spill1 && at < a.ovf_cap) ovf[at] = make_uint2(qi1, __float_as_uint(qd1));
+                if (spill1 && at < ovf_cap) ovf[at] = make_uint2(qi1, __float_as_uint(qd1));
                 ovf_n += __popcll(sm1);
               }
               const bool spill0 = two && np0 >= ef;
               const uint64_t sm0 = __ballot(spill0);
               if (sm0) {
                 const uint32_t at = ovf_n + __popcll(sm0 & lt);
-                if (spill0 && at < a.ovf_cap) ovf[at] = make_uint2(qi0, __float_as_uint(qd0));
+                if (spill0 && at < ovf_cap) ovf[at] = make_uint2(qi0, __float_as_uint(qd0));
                 ovf_n += __popcll(sm0);
               }
             }
@@ -492,7 +505,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           uint64_t sm = __ballot(spill);
           if (sm) {
             uint32_t at = ovf_n + __popcll(sm & lt);
-            if (spill && at < a.ovf_cap) ovf[at] = make_uint2(nb, __float_as_uint(myd));
+            if (spill && at < ovf_cap) ovf[at] = make_uint2(nb, __float_as_uint(myd));
             ovf_n += __popcll(sm);
           }
         }
@@ -500,7 +513,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         scan_from = min(pop >= 0 ? (uint32_t)pop + 1u : scan_from, pos_min);
         __syncthreads();
         PH_TICK(4)
-        if (ovf_n > a.ovf_cap) {
+        if (ovf_n > ovf_cap) {
           err = ST_OVERFLOW;
           break;
         }
@@ -641,8 +654,9 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     }
 
     if (err != ST_OK) {
-      // leave the slot clean for the next query: wipe the whole bitmap (rare path)
-      for (uint64_t w = lane; w < a.visited_words; w += 64) vis[w] = 0u;
+      // leave the slot clean for the next query: wipe the whole bitmap (rare path; a dense-only launch has none)
+      if (!DENSE_ONLY)
+        for (uint64_t w = lane; w < a.visited_words; w += 64) vis[w] = 0u;
       wait_vm0();
       clen = 0;
     }
@@ -710,6 +724,14 @@ __global__ __launch_bounds__(64) void ph_search_kernel(PhSearchArgs a) {
   ph_search_body<CAPC, Dist>(a);
 }
 
+// The dense top layers in a launch of their own: no distance policy state, so half the registers and (queues of
+// ef <= 256 in 256 slots) half the LDS of the full kernel -- twice the resident waves on a walk that is pure
+// latency and instruction issue.  The running candidates are parked in the output rows for the follow-up launch.
+template <int CAPC>
+__global__ __launch_bounds__(64) void ph_search_kernel_dense(PhSearchArgs a) {
+  ph_search_body<CAPC, DistNone>(a);
+}
+
 // Small batches leave most of the chip idle and finish with their slowest query: their kernels keep up to 24
 // rows in flight per wave (one load round per hop instead of up to twelve) at one wave per SIMD.  Same
 // arithmetic per row, so the same results.
@@ -729,6 +751,7 @@ __global__ __launch_bounds__(64, 2) void ph_search_kernel_pqr(PhSearchArgs a) {
 typedef void (*ph_search_fn)(PhSearchArgs);
 
 static int pick_capc(uint32_t ef) { return ef <= 128 ? 2 : (ef <= 512 ? 8 : (ef <= 1024 ? 16 : 0)); }
+static int pick_capc_dense(uint32_t ef) { return ef <= 128 ? 2 : (ef <= 256 ? 4 : (ef <= 512 ? 8 : (ef <= 1024 ? 16 : 0))); }
 static int pick_nv(uint32_t nv4) { return nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : (nv4 <= 384 ? 6 : 0)); }
 
 // the register-table policy serves 8-bit tables (mode 2) of exactly 32 / 64 / 96 / 128 sub-spaces with at most
@@ -753,6 +776,16 @@ static ph_search_fn pick_kernel_pqs(int capc, int nv) {
   if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, DistPQS<N>>;
   PH_KS(2, 1) PH_KS(2, 3) PH_KS(2, 6) PH_KS(8, 1) PH_KS(8, 3) PH_KS(8, 6)
 #undef PH_KS
+  return nullptr;
+}
+
+static ph_search_fn pick_kernel_dense(int capc) {
+  switch (capc) {
+    case 2: return (ph_search_fn)ph_search_kernel_dense<2>;
+    case 4: return (ph_search_fn)ph_search_kernel_dense<4>;
+    case 8: return (ph_search_fn)ph_search_kernel_dense<8>;
+    case 16: return (ph_search_fn)ph_search_kernel_dense<16>;
+  }
   return nullptr;
 }
 
@@ -821,6 +854,7 @@ void ph_workspace_free(PhWorkspace &ws) {
   for (auto &e : ws.evd)
     if (e) hipEventDestroy(e);
   if (ws.dtotals) hipFree(ws.dtotals);
+  if (ws.dense_ovf) hipFree(ws.dense_ovf);
   ph_workspace_order_free(ws);
   ph_tiny_free(ws);
   ws = PhWorkspace();
@@ -886,7 +920,59 @@ int ph_search_begin(PhWorkspace &ws, hipStream_t stream) {
   return 0;
 }
 
+template <class T>
+static hipError_t grow_buf(T **p, size_t *have, size_t need) {
+  if (*have >= need) return hipSuccess;
+  if (*p) hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  hipError_t e = hipMalloc((void **)p, need);
+  if (e == hipSuccess) *have = need;
+  return e;
+}
+
+// the dense-only launch of a descent (PhSearchArgs::dense_only): its own kernel, grid and spill lists
+static int search_launch_dense(PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream) {
+  const int capc = pick_capc_dense(a.ef);
+  ph_search_fn fn = pick_kernel_dense(capc);
+  if (!fn) {
+    ph_set_error("unsupported search shape: ef=%u", a.ef);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  const size_t lds = lds_bytes(capc, ph_tiny_lds_bytes(a));
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    PH_HIP(hipGetDevice(&dev));
+    PH_HIP(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+  per_cu = std::min(per_cu, 32);
+  if (const char *e = getenv("PHNSW_DENSE_WAVES_PER_CU"))
+    if (atoi(e) > 0) per_cu = atoi(e);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * cus, a.nq);
+  if (grid == 0) return 0;
+  // a layer of the table cannot evaluate more nodes than the table has: spill lists of tiny_stride entries never overflow
+  a.dense_ovf_cap = a.tiny_stride;
+  PH_HIP(grow_buf(&ws.dense_ovf, &ws.dense_ovf_bytes, (size_t)grid * a.dense_ovf_cap * sizeof(uint2)));
+  a.dense_ovf = ws.dense_ovf;
+  a.visited = ws.visited;  // never touched: the visited set of a dense layer is in LDS
+  a.visited_words = 0;
+  a.ovf = ws.ovf;
+  a.ovf_cap = ws.ovf_cap;
+  a.counter = ws.counter;
+  PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));
+  a.seg = a.order ? (a.nq + 7u) / 8u : 0u;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a);
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end) {
+  if (a.dense_only) return search_launch_dense(ws, a, stream);
   const bool pq = ix->store->codes != nullptr;
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
   const int pqr = ix->store->codes16 ? -1 : pick_pqr(ix->store, capc);

@@ -156,3 +156,83 @@ def test_matrix_core_table_equals_vector_unit_table():
     finally:
         del os.environ["PHNSW_TINY_VALU"]
     same(a, b)
+
+
+class no_dense_split:
+    """PHNSW_NO_DENSE_SPLIT=1: the dense top layers stay in the full kernel's first launch"""
+
+    def __enter__(self):
+        os.environ["PHNSW_NO_DENSE_SPLIT"] = "1"
+
+    def __exit__(self, *a):
+        del os.environ["PHNSW_NO_DENSE_SPLIT"]
+
+
+class split_bytes:
+    """PHNSW_SPLIT_BYTES: layers above this many row bytes get a launch of their own in a split descent"""
+
+    def __init__(self, n):
+        self.n = str(n)
+
+    def __enter__(self):
+        os.environ["PHNSW_SPLIT_BYTES"] = self.n
+
+    def __exit__(self, *a):
+        del os.environ["PHNSW_SPLIT_BYTES"]
+
+
+@pytest.mark.parametrize("ef,dim", [(104, 768), (256, 96), (300, 256), (600, 64)])
+def test_dense_layers_in_a_launch_of_their_own(ef, dim):
+    """split descents (batches of >= 32768 queries) walk their dense top layers in ph_search_kernel_dense (queues of
+    128 / 256 / 512 / 1024 slots) and continue in the full kernel from the parked candidates: same results as with
+    the dense layers in the full kernel's first launch, as the per-hop path, as the oracle"""
+    n, nq = 9000, 33000
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters(seed=13, max_link_rounds=1))
+    q = oracle.synth_rows(2 ** 32, nq, dim)[:, :dim]
+    sp = ph.SearchParameters(ef, ef, 3)
+    with split_bytes(100000):
+        two = h.search_batch(queries=q, sp=sp, stats=True)
+        disp = h.dispatches()
+        assert len(disp) >= 3 and disp[1]["layers"][0] == 0 and disp[2]["layers"][0] == disp[1]["layers"][1], disp
+        with no_dense_split():
+            one = h.search_batch(queries=q, sp=sp, stats=True)
+        same(two, one)
+        with per_hop_path():
+            same(two, h.search_batch(queries=q, sp=sp, stats=True))
+    same(two, h.search_batch(queries=q, sp=sp, stats=True))  # and the unsplit descent
+    ix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    for l in h.layers:
+        ix.push_layer(l.nodes, l.neighbors, l.neighborhood_size)
+    ci, cd, cl, cs = ix.search(queries=q[:500], sp=(ef, ef, 3), stats=True)
+    np.testing.assert_array_equal(two[0][:500], ci)
+    np.testing.assert_array_equal(two[1][:500].view(np.uint32), cd.view(np.uint32))
+    np.testing.assert_array_equal(two[3][:500], cs)
+
+
+def test_not_nested_layers_with_a_dense_first_launch():
+    """the table's usable flag is only known on the device: with layers that are not nested the dense launch does
+    nothing and the follow-up launch walks every layer per hop -- same error as the per-hop path"""
+    n, dim = 64, 16
+    rows = oracle.synth_rows(0, n, dim)[:, :dim]
+    store = ph.VectorStore(rows)
+    E = ph.EMPTY
+    top = (np.array([5, 9], dtype=np.uint64), np.array([[1, E], [0, E]], dtype=np.uint64))
+    low_nodes = np.array([3, 9, 20, 40], dtype=np.uint64)  # 5 is missing
+    low = (low_nodes, np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]], dtype=np.uint64))
+    h = ph.Hnsw.from_layers(store, [top, low])
+    q = oracle.synth_rows(2 ** 32, 33000, dim)[:, :dim]
+    with split_bytes(1):
+        with pytest.raises(ph.PhnswError) as e1:
+            h.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2))
+        with per_hop_path():
+            with pytest.raises(ph.PhnswError) as e2:
+                h.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2))
+        assert e1.value.code == e2.value.code
+        # the nested graph of the same shapes: dense launch + follow-up == one launch
+        low2 = (np.array([5, 9, 20, 40], dtype=np.uint64), low[1])
+        h2 = ph.Hnsw.from_layers(store, [top, low2])
+        r2 = h2.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2), stats=True)
+        with no_dense_split():
+            same(r2, h2.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2), stats=True))
