@@ -223,29 +223,35 @@ def worker(args):
         return index, info
 
     def sharded_probe(store, index, emit):
-        """index construction sharded over the ranks (node ranges per round, RCCL all-gather of the per-node results:
-        parallel_hnsw_amd/sharded.py), timed, and compared with this rank's own build.  The RCCL path could
-        not be exercised on the one-GPU development boxes, so it runs AFTER the search measurement and under a
-        watchdog: if it does not finish in --sharded-timeout seconds, rank 0 prints the line without it and every rank
-        leaves (a hung collective must not cost the search numbers)."""
+        """index construction sharded over the ranks: phnsw_build_sharded (csrc/sharded.hip) over the library's own
+        RCCL transport -- node ranges per round, ncclAllGather of the per-node results on the collectives' stream
+         -- timed, and compared with this rank's own build.  It runs AFTER the search measurement and
+        under a watchdog: if it does not finish in --sharded-timeout seconds, rank 0 prints the line without it and
+        every rank leaves with exit code 3 (a hung collective must neither cost the search numbers nor pass for a
+        successful run)."""
         import threading
+        from parallel_hnsw_amd.sharded import build_sharded
         finished = threading.Event()
 
         def watchdog():
             if not finished.wait(args.sharded_timeout):
                 if rank == 0:
-                    emit({"error": "sharded build did not finish within %d s; line printed without it" % args.sharded_timeout})
-                os._exit(0)
+                    emit({"error": "sharded build did not finish within %d s; line printed without it, exit code 3"
+                                   % args.sharded_timeout})
+                sys.stderr.flush()
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         out = {}
         try:
+            comm = ph.TorchComm()
+            cc = comm.c_comm(local)   # nccl backend: phnsw_comm_rccl_create, the id travels through the group
+            from parallel_hnsw_amd._lib import check
+            check(ph.lib().phnsw_comm_selftest(cc, 1 << 20))
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.time()
-            eng = ph.GpuEngine(store, ph.BuildParameters(), device=dev)
-            comm = ph.TorchComm()
-            sh = ph.ShardedBuilder(eng, comm).generate(np.arange(store.n, dtype=np.uint64))
+            sh, st = build_sharded(store, np.arange(store.n, dtype=np.uint64), ph.BuildParameters(), comm)
             torch.cuda.synchronize()
             dist.barrier()
             secs = time.time() - t0
@@ -255,9 +261,15 @@ def worker(args):
                 same = same and np.array_equal(a_.nodes, b_.nodes) and np.array_equal(a_.neighbors, b_.neighbors)
             out = {"ranks": world, "seconds": round(secs, 3), "vectors_per_s": round(store.n / secs, 1),
                    "identical_to_single_gpu_build": bool(same),
-                   "all_gather": {"bytes_per_rank": comm.bytes_gathered, "seconds": round(comm.seconds, 4),
-                                  "collectives": getattr(comm, "calls", None)}}
+                   "driver": "phnsw_build_sharded (C ABI) over %s" % ("phnsw_comm_rccl (ncclAllGather)" if backend == "nccl"
+                                                                      else "host callbacks (%s)" % backend),
+                   "rank0_seconds": {k: round(v, 4) for k, v in st.items() if k.startswith("seconds")},
+                   "phases": st["phases"], "phases_not_split": st["phases_whole"],
+                   "all_gather": {"bytes_received_per_rank": st["all_gather_bytes"], "collectives": st["all_gather_calls"],
+                                  "host_seconds_in_collectives_waits_and_reassembly": round(st["seconds_comm"], 4),
+                                  "all_reduces": st["all_reduce_calls"]}}
             log("sharded build x%d: %.1f s (%.0f vectors/s), identical to the single-GPU graph: %s" % (world, secs, store.n / secs, same))
+            comm.close()
         except Exception as exc:  # say what happened; the search numbers stand
             out = {"error": repr(exc)}
             log("sharded build failed: %r" % (exc,))
@@ -549,8 +561,15 @@ def worker(args):
     else:
         line = None
 
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
+
     def emit(sharded=None):
-        if line is not None:
+        """prints the line exactly once (the watchdog thread and the main thread may both arrive here)"""
+        with emit_lock:
+            if line is None or emitted[0]:
+                return
+            emitted[0] = True
             if sharded is not None:
                 line["sharded_build"] = sharded
                 if "all_gather" in sharded:

@@ -262,6 +262,109 @@ int phnsw_promote_at_layer_hits_device(phnsw_index *ix, uint32_t layer_from_top,
 int phnsw_recall_hits(phnsw_index *ix, uint32_t layer_from_top, const phnsw_optimization_params *op,
                       uint64_t first, uint64_t count, uint64_t *out_hits, uint64_t *out_selection);
 
+/* ---- sharded build: Hnsw::generate / improve_index with every per-node phase split over the GPUs
+ * of one node (BASELINE config 4).  One process per GPU; every rank holds a replica of
+ * store and graph; within a round nodes are independent (the searches of lib.rs:1107-1117 read a
+ * snapshot), so rank r runs the phase for the node range [r*chunk, (r+1)*chunk), the per-node results
+ * (u32 ids + f32 distances) are all-gathered, and every rank applies ALL of them (K5): replicas stay
+ * bit-identical and the graph equals phnsw_build's.  Control flow = lib.rs:825-893, 1515-1686.
+ *
+ * phnsw_comm is the collective seam: a host supplies its own transport (MPI, a torch.distributed
+ * group, ...) as two callbacks, or takes the built-in RCCL one (phnsw_comm_rccl_create: ncclAllGather
+ * over xGMI on a stream of the library's, no torch).
+ *   all_gather: every rank contributes `bytes` at `send`; `recv` receives world*bytes in rank order.
+ *     host_buffers == 0: device pointers; the call ENQUEUES on `stream` (a hipStream_t) and may return
+ *     before the transfer is done -- the library overlaps it with the next piece's searches and
+ *     synchronises the stream itself.  host_buffers == 1: host pointers (the library stages through
+ *     pinned memory), stream is NULL, the call returns when recv is complete.
+ *   all_reduce_sum: element-wise sum of `count` host u64 over the ranks, in place.
+ *   emulate != 0 with all_gather == NULL: ONE process plays all `world` ranks in turn on its GPU (every
+ *     range is computed here, in rank order, with the same split, packing and reassembly): what the
+ *     one-GPU tests and the scaling model of bench.py use; phnsw_sharded_stats separates rank `rank`'s
+ *     time from the others'. */
+typedef int (*phnsw_all_gather_fn)(void *ctx, const void *send, void *recv, uint64_t bytes, void *stream);
+typedef int (*phnsw_all_reduce_sum_fn)(void *ctx, uint64_t *values, uint32_t count);
+typedef struct phnsw_comm {
+  uint32_t rank, world;
+  uint32_t host_buffers;
+  uint32_t emulate;
+  void *ctx;
+  phnsw_all_gather_fn all_gather;
+  phnsw_all_reduce_sum_fn all_reduce_sum;
+} phnsw_comm;
+
+/* where a sharded build spent its time (seconds on the calling rank) and what it moved */
+typedef struct phnsw_sharded_stats {
+  double seconds_total;
+  double seconds_sharded;    /* this rank's share of the per-node phases (searches, seeding) */
+  double seconds_replicated; /* phases every rank repeats (row merges K5, layer bookkeeping, promotion) */
+  double seconds_comm;       /* host time inside collectives, their waits and the reassembly copies */
+  double seconds_others;     /* emulate: the other ranks' shares, computed here in turn */
+  uint64_t all_gather_bytes; /* received, summed over calls */
+  uint64_t all_gather_calls;
+  uint64_t all_reduce_calls;
+  uint64_t phases;           /* sharded phases run */
+  uint64_t phases_whole;     /* work lists too short to split (every rank ran them whole, no collective) */
+} phnsw_sharded_stats;
+
+/* Hnsw::generate (lib.rs:825-893) over the ranks of `comm`; comm == NULL or world == 1 is phnsw_build.
+ * Every rank must call it with the same store contents, vids and bp.  stats nullable. */
+int phnsw_build_sharded(phnsw_store *s, const uint64_t *vids, uint64_t n, const phnsw_build_params *bp,
+                        const phnsw_comm *comm, phnsw_progress_cb cb, void *user, phnsw_index **out,
+                        phnsw_sharded_stats *stats);
+/* Hnsw::improve_index (lib.rs:1664-1686) on an existing, replicated index */
+int phnsw_improve_index_sharded(phnsw_index *ix, const phnsw_build_params *bp, float last_recall,
+                                const phnsw_comm *comm, float *out_recall, phnsw_sharded_stats *stats);
+/* work lists shorter than shard_min run whole on every rank (default 4096); a rank's share is cut into
+ * `subchunks` pieces of at least sub_min items whose all-gathers overlap the next piece (defaults 4, 8192).
+ * 0 keeps a value.  Process-wide; for tests and tuning. */
+int phnsw_sharded_tuning(uint64_t shard_min, uint32_t subchunks, uint64_t sub_min);
+
+/* the built-in transport: RCCL (librccl is loaded on first use; PHNSW_RCCL_LIB overrides its path).
+ * Rank 0 makes the 128-byte id, the host hands it to the other ranks by any means, every rank creates
+ * its communicator on its own device.  The returned phnsw_comm has host_buffers == 0. */
+int phnsw_comm_rccl_unique_id(uint8_t *out_id128);
+int phnsw_comm_rccl_create(const uint8_t *id128, uint32_t rank, uint32_t world, int device, phnsw_comm **out);
+void phnsw_comm_destroy(phnsw_comm *c);
+/* checks a communicator end to end before a build is trusted to it: every rank contributes a known pattern of
+ * `bytes` bytes, verifies all world blocks of the all-gather, then the all-reduce.  Collective: every rank calls it. */
+int phnsw_comm_selftest(const phnsw_comm *comm, uint64_t bytes);
+
+/* The phase engine behind the sharded driver.  phnsw_build_sharded runs the driver over libphnsw's own
+ * GPU phases (the phase API above); this entry runs the SAME driver over an engine given as callbacks,
+ * which is how the CPU tests drive it under gloo with the oracle's phases (tests/test_sharded_gloo.py).
+ * ids / lengths / hit flags are id_bytes wide (4 or 8), distances f32; host_buffers: alloc returns host
+ * memory (then comm->host_buffers must be 1 too). */
+typedef struct phnsw_shard_engine {
+  void *ctx;
+  uint32_t id_bytes;
+  uint32_t host_buffers;
+  void *(*alloc)(void *ctx, uint64_t bytes);
+  void (*release)(void *ctx, void *p);
+  int (*copy2d)(void *ctx, void *dst, uint64_t dpitch, const void *src, uint64_t spitch, uint64_t width,
+                uint64_t height);
+  int (*plan)(void *ctx, const uint64_t *vids, uint64_t n, uint64_t *shuffled, uint64_t *layer_sizes,
+              uint32_t max_layers, uint32_t *layer_count);
+  int (*layer_begin)(void *ctx, const uint64_t *vids, uint64_t n, uint64_t W, int *needs_phases, uint32_t *K);
+  int (*layer_init_search)(void *ctx, uint64_t first, uint64_t count, void *ids, float *d, void *len);
+  int (*layer_seed)(void *ctx, const void *init_ids, const float *init_d, const void *init_len, uint64_t first,
+                    uint64_t count, void *rows, float *rows_d);
+  int (*layer_finish)(void *ctx, const void *rows, const float *rows_d);
+  uint32_t (*layer_count)(void *ctx);
+  uint64_t (*layer_nodes)(void *ctx, uint32_t layer_from_top);
+  int (*link_search)(void *ctx, uint32_t layer_from_top, const phnsw_search_params *sp, uint64_t link_count,
+                     uint64_t first, uint64_t count, void *ids, float *d, void *len);
+  int (*link_apply)(void *ctx, uint32_t layer_from_top, uint64_t link_count, const void *ids, const float *d,
+                    const void *len, uint64_t *added);
+  int (*recall_hits)(void *ctx, uint32_t layer_from_top, const phnsw_optimization_params *op, uint64_t first,
+                     uint64_t count, uint64_t *hits, uint64_t *selection);
+  int (*discover_hits)(void *ctx, uint32_t layer_from_top, const phnsw_search_params *sp, uint64_t first,
+                       uint64_t count, void *hit);
+  int (*promote_from_hits)(void *ctx, uint32_t layer_from_top, const void *hit, int *promoted);
+} phnsw_shard_engine;
+int phnsw_build_sharded_engine(const phnsw_shard_engine *e, const uint64_t *vids, uint64_t n,
+                               const phnsw_build_params *bp, const phnsw_comm *comm, phnsw_sharded_stats *stats);
+
 /* ---- product quantisation (reference src/pq.rs; BASELINE config 5) ----
  * A PQ store holds u8 code rows [n][m] over per-sub-space codebooks [m][ksub][dim/m]
  * (random_centroids pq.rs:261-285 per sub-space; Quantizer::quantize pq.rs:61-71 as the exact

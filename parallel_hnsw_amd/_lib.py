@@ -40,6 +40,50 @@ class BuildParams(C.Structure):
 
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64)
 
+# ---- sharded build (include/phnsw.h: phnsw_comm, phnsw_sharded_stats, phnsw_shard_engine)
+AllGatherFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+AllReduceFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
+
+
+class Comm(C.Structure):
+    """phnsw_comm"""
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("host_buffers", C.c_uint32), ("emulate", C.c_uint32),
+                ("ctx", C.c_void_p), ("all_gather", AllGatherFn), ("all_reduce_sum", AllReduceFn)]
+
+
+class ShardedStats(C.Structure):
+    """phnsw_sharded_stats"""
+    _fields_ = [("seconds_total", C.c_double), ("seconds_sharded", C.c_double), ("seconds_replicated", C.c_double),
+                ("seconds_comm", C.c_double), ("seconds_others", C.c_double), ("all_gather_bytes", C.c_uint64),
+                ("all_gather_calls", C.c_uint64), ("all_reduce_calls", C.c_uint64), ("phases", C.c_uint64),
+                ("phases_whole", C.c_uint64)]
+
+
+_vpx, _u64x, _u32x = C.c_void_p, C.c_uint64, C.c_uint32
+
+
+class ShardEngine(C.Structure):
+    """phnsw_shard_engine: the phases behind the sharded driver as callbacks (raw pointers as ints)"""
+    _fields_ = [
+        ("ctx", C.c_void_p), ("id_bytes", C.c_uint32), ("host_buffers", C.c_uint32),
+        ("alloc", C.CFUNCTYPE(C.c_void_p, _vpx, _u64x)),
+        ("release", C.CFUNCTYPE(None, _vpx, _vpx)),
+        ("copy2d", C.CFUNCTYPE(C.c_int, _vpx, _vpx, _u64x, _vpx, _u64x, _u64x, _u64x)),
+        ("plan", C.CFUNCTYPE(C.c_int, _vpx, _vpx, _u64x, _vpx, _vpx, _u32x, C.POINTER(C.c_uint32))),
+        ("layer_begin", C.CFUNCTYPE(C.c_int, _vpx, _vpx, _u64x, _u64x, C.POINTER(C.c_int), C.POINTER(C.c_uint32))),
+        ("layer_init_search", C.CFUNCTYPE(C.c_int, _vpx, _u64x, _u64x, _vpx, _vpx, _vpx)),
+        ("layer_seed", C.CFUNCTYPE(C.c_int, _vpx, _vpx, _vpx, _vpx, _u64x, _u64x, _vpx, _vpx)),
+        ("layer_finish", C.CFUNCTYPE(C.c_int, _vpx, _vpx, _vpx)),
+        ("layer_count", C.CFUNCTYPE(C.c_uint32, _vpx)),
+        ("layer_nodes", C.CFUNCTYPE(C.c_uint64, _vpx, _u32x)),
+        ("link_search", C.CFUNCTYPE(C.c_int, _vpx, _u32x, C.POINTER(SearchParams), _u64x, _u64x, _u64x, _vpx, _vpx, _vpx)),
+        ("link_apply", C.CFUNCTYPE(C.c_int, _vpx, _u32x, _u64x, _vpx, _vpx, _vpx, C.POINTER(C.c_uint64))),
+        ("recall_hits", C.CFUNCTYPE(C.c_int, _vpx, _u32x, C.POINTER(OptimizationParams), _u64x, _u64x,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))),
+        ("discover_hits", C.CFUNCTYPE(C.c_int, _vpx, _u32x, C.POINTER(SearchParams), _u64x, _u64x, _vpx)),
+        ("promote_from_hits", C.CFUNCTYPE(C.c_int, _vpx, _u32x, _vpx, C.POINTER(C.c_int))),
+    ]
+
 # name -> (restype, argtypes): every symbol include/phnsw.h declares
 _vp, _u64, _u32, _i32, _f32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float
 _pp = C.POINTER(C.c_void_p)
@@ -91,6 +135,17 @@ SYMBOLS = {
     "phnsw_promote_at_layer_hits_device": (_i32, [_vp, _u32, C.POINTER(BuildParams), _vp, C.POINTER(_i32)]),
     "phnsw_recall_hits": (_i32, [_vp, _u32, C.POINTER(OptimizationParams), _u64, _u64, C.POINTER(_u64),
                                  C.POINTER(_u64)]),
+    "phnsw_build_sharded": (_i32, [_vp, _vp, _u64, C.POINTER(BuildParams), C.POINTER(Comm), PROGRESS_CB, _vp, _pp,
+                                   C.POINTER(ShardedStats)]),
+    "phnsw_improve_index_sharded": (_i32, [_vp, C.POINTER(BuildParams), _f32, C.POINTER(Comm), C.POINTER(_f32),
+                                           C.POINTER(ShardedStats)]),
+    "phnsw_sharded_tuning": (_i32, [_u64, _u32, _u64]),
+    "phnsw_comm_rccl_unique_id": (_i32, [_vp]),
+    "phnsw_comm_rccl_create": (_i32, [_vp, _u32, _u32, _i32, C.POINTER(C.POINTER(Comm))]),
+    "phnsw_comm_destroy": (None, [C.POINTER(Comm)]),
+    "phnsw_comm_selftest": (_i32, [C.POINTER(Comm), _u64]),
+    "phnsw_build_sharded_engine": (_i32, [C.POINTER(ShardEngine), _vp, _u64, C.POINTER(BuildParams), C.POINTER(Comm),
+                                          C.POINTER(ShardedStats)]),
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),
     "phnsw_store_create_pq_kmeans": (_i32, [_vp, _u32, _u32, _u64, _u32, _u64, _pp]),
     "phnsw_store_create_pq_shared": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(BuildParams), C.POINTER(SearchParams), _i32, _pp]),

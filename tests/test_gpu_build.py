@@ -149,90 +149,51 @@ def test_build_rejects_bad_input():
         ph.Hnsw.generate(store, np.arange(9), gbp(zero_layer_neighborhood_size=65))
 
 
-def test_sharded_builder_single_rank_equals_phnsw_build():
-    """parallel_hnsw_amd.sharded (the multi-GPU driver) on one rank: same phases, same graph
-    as phnsw_build and as the oracle; the 2-rank split itself is covered on CPU (gloo)"""
+def test_sharded_build_emulated_worlds_equal_phnsw_build():
+    """phnsw_build_sharded (csrc/sharded.hip) with one process playing every rank in turn: each rank's node range
+    runs as its own launches through the phase API, the blocks are laid out and reassembled as over RCCL, and the
+    graph must be phnsw_build's and the oracle's -- for worlds that divide the layers unevenly, with the share of
+    a rank cut into pieces (the sub-chunk pipeline), and with short lists kept whole"""
+    from parallel_hnsw_amd.sharded import EmulatedComm, build_sharded, sharded_tuning
     n, dim = 3000, 64
     rows = oracle.synth_rows(0, n, dim)
     store = ph.VectorStore(rows[:, :dim])
-    eng = ph.GpuEngine(store, gbp(seed=4))
-
-    class OneRank:
-        rank, world, bytes_gathered = 0, 1, 0
-
-        def all_gather(self, t):
-            return t
-
-        def all_reduce_sum(self, v, device):
-            return list(v)
-
-    h = ph.ShardedBuilder(eng, OneRank()).generate(np.arange(n))
     ref = ph.Hnsw.generate(store, np.arange(n), gbp(seed=4))
-    assert h.layer_count() == ref.layer_count()
-    for l in range(ref.layer_count()):
-        a, b = h._layer(l), ref._layer(l)
-        np.testing.assert_array_equal(a.nodes, b.nodes)
-        np.testing.assert_array_equal(a.neighbors, b.neighbors)
     oix = oracle.Index.generate(rows, np.arange(n), obp(seed=4), dim=dim, sum_mode=oracle.SUM_BLOCKED64)
-    layers_equal(h, oix)
+    layers_equal(ref, oix)
+    try:
+        for world, rank, shard_min, subchunks, sub_min in ((2, 0, 1, 1, 1), (3, 1, 1, 4, 64), (8, 7, 256, 4, 16),
+                                                           (5, 0, 4096, 4, 8192)):
+            sharded_tuning(shard_min, subchunks, sub_min)
+            h, st = build_sharded(store, np.arange(n), gbp(seed=4), EmulatedComm(world, rank))
+            assert h.layer_count() == ref.layer_count()
+            for l in range(ref.layer_count()):
+                a, b = h._layer(l), ref._layer(l)
+                np.testing.assert_array_equal(a.nodes, b.nodes)
+                np.testing.assert_array_equal(a.neighbors, b.neighbors, err_msg="world %d layer %d" % (world, l))
+            if shard_min < 4096:
+                assert st["all_gather_calls"] > 0 and st["seconds_others"] > 0
+            else:
+                assert st["all_gather_calls"] == 0  # nothing at this size is long enough to split
+    finally:
+        sharded_tuning(4096, 4, 8192)
 
 
-def test_phase_api_ranges_compose():
-    """two half ranges through the phase API == one full range (what two GPUs would compute)"""
-    import torch
-    n, dim = 2000, 32
-    rows = oracle.synth_rows(0, n, dim)
-    store = ph.VectorStore(rows[:, :dim])
-    ref = ph.Hnsw.generate(store, np.arange(n), gbp(seed=2))
-
-    class TwoHalves:
-        """runs the driver twice per phase on one GPU by faking rank 0 then rank 1"""
-        bytes_gathered = 0
-
-        def __init__(self):
-            self.rank, self.world = 0, 1
-
-        def all_gather(self, t):
-            return t
-
-        def all_reduce_sum(self, v, device):
-            return list(v)
-
-    eng = ph.GpuEngine(store, gbp(seed=2))
-    b = ph.ShardedBuilder(eng, TwoHalves())
-    orig_range = b._range
-
-    # monkeypatch the phase calls to split every range in two launches
-    def split(fn, first_idx, count_idx):
-        def wrapped(*a):
-            a = list(a)
-            first, count = a[first_idx], a[count_idx]
-            h1 = count // 2
-            outs = [x for x in a if isinstance(x, torch.Tensor) and x.shape[0] == count and x is not None]
-            a1 = list(a); a1[count_idx] = h1
-            a2 = list(a); a2[first_idx] = first + h1; a2[count_idx] = count - h1
-            # output tensors are the trailing tensor args: give the second half offset views
-            for i, x in enumerate(a):
-                if i > count_idx and isinstance(x, torch.Tensor):
-                    a1[i] = x[:h1]
-                    a2[i] = x[h1:]
-            fn(*a1)
-            fn(*a2)
-        return wrapped
-
-    eng.layer_init_search = split(eng.layer_init_search, 0, 1)
-    eng.link_search = split(eng.link_search, 3, 4)
-    seed0 = eng.layer_seed
-
-    def seed_split(ids, d, ln, first, count, rows_, rows_d):
-        h1 = count // 2
-        seed0(ids, d, ln, first, h1, rows_[:h1], rows_d[:h1])
-        seed0(ids, d, ln, first + h1, count - h1, rows_[h1:], rows_d[h1:])
-
-    eng.layer_seed = seed_split
-    h = b.generate(np.arange(n))
-    for l in range(ref.layer_count()):
-        np.testing.assert_array_equal(h._layer(l).neighbors, ref._layer(l).neighbors)
+def test_rccl_transport_selftest_single_rank():
+    """the library's own RCCL transport (phnsw_comm_rccl_*; librccl loaded on first use): on the one GPU of the
+    test box a world of one rank still runs ncclCommInitRank, ncclAllGather on the library's stream and
+    ncclAllReduce end to end"""
+    import ctypes as C
+    from parallel_hnsw_amd._lib import Comm, check
+    ident = (C.c_uint8 * 128)()
+    check(ph.lib().phnsw_comm_rccl_unique_id(ident))
+    p = C.POINTER(Comm)()
+    check(ph.lib().phnsw_comm_rccl_create(ident, 0, 1, 0, C.byref(p)))
+    try:
+        assert p.contents.world == 1 and p.contents.host_buffers == 0
+        check(ph.lib().phnsw_comm_selftest(p, 1 << 20))
+    finally:
+        ph.lib().phnsw_comm_destroy(p)
 
 
 def _two_rank_worker(rank, world, port, out_dir):
@@ -245,8 +206,13 @@ def _two_rank_worker(rank, world, port, out_dir):
         n, dim = 3000, 64
         store = ph.VectorStore.synthetic(n, dim, seed=42)
         eng = ph.GpuEngine(store, ph.BuildParameters(seed=6))
-        comm = ph.TorchComm()
-        h = ph.ShardedBuilder(eng, comm, shard_min=256).generate(np.arange(n))  # split all but the tiny layers
+        comm = ph.TorchComm()   # gloo: host callbacks, libphnsw stages its device blocks through pinned memory
+        from parallel_hnsw_amd._lib import check
+        check(ph.lib().phnsw_comm_selftest(comm.c_comm(0), 4096))
+        before = comm.bytes_gathered
+        b = ph.ShardedBuilder(eng, comm, shard_min=256)  # split all but the tiny layers
+        h = b.generate(np.arange(n))
+        assert b.stats["all_gather_bytes"] == comm.bytes_gathered - before > 0
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered,
                  **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
     finally:
@@ -353,21 +319,26 @@ def _nccl_worker(rank, world, port, out_dir):
         n, dim = 40000, 64
         store = ph.VectorStore.synthetic(n, dim, seed=42, device=rank)
         eng = ph.GpuEngine(store, ph.BuildParameters(seed=6, max_link_rounds=1), device=torch.device("cuda", rank))
-        comm = ph.TorchComm()
-        b = ph.ShardedBuilder(eng, comm, shard_min=256)
-        b.SUB_MIN = 1024  # the bottom layer's share is cut into pieces whose all-gathers run asynchronously
+        comm = ph.TorchComm()   # nccl: the library's own RCCL communicator, the id travels through the group
+        from parallel_hnsw_amd._lib import check
+        check(ph.lib().phnsw_comm_selftest(comm.c_comm(rank), 1 << 20))
+        # the bottom layer's share is cut into pieces whose all-gathers run on the collectives' stream
+        b = ph.ShardedBuilder(eng, comm, shard_min=256, sub_min=1024)
         h = b.generate(np.arange(n))
         torch.cuda.synchronize()
-        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered, calls=comm.calls,
+        comm.close()
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=b.stats["all_gather_bytes"],
+                 calls=b.stats["all_gather_calls"],
                  **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_build_over_rccl(tmp_path):
-    """one process per GPU, torch.distributed 'nccl' (= RCCL over xGMI), asynchronous all-gathers of the
-    sub-chunk pipeline: every rank ends with the graph one GPU builds.  Needs two GPUs; the one-GPU test
-    boxes skip it (the gloo rehearsal above covers the device side there)."""
+    """one process per GPU, phnsw_build_sharded over the library's RCCL transport (ncclAllGather over xGMI on the
+    collectives' stream, pieces of the sub-chunk pipeline in flight): every rank ends with the graph one GPU
+    builds.  Needs two GPUs; the one-GPU test boxes skip it (there: the RCCL self-test with one rank, the gloo
+    rehearsal with two, and the emulated worlds above)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs at least two GPUs (RCCL: one rank per GPU)")

@@ -1,7 +1,8 @@
-"""The N>1 build path on CPU: parallel_hnsw_amd.sharded.ShardedBuilder under a world_size-2
-`gloo` group with the oracle as the engine.  Checks the range split, padding, all-gather
-assembly and the replicated control flow: both ranks must end with exactly the graph a
-single process builds."""
+"""The N>1 build path on CPU: libphnsw's sharded driver (csrc/sharded.hip, the loop behind phnsw_build_sharded)
+run through phnsw_build_sharded_engine with the ORACLE's phases as the engine -- under world_size-2 and -3 `gloo`
+groups (host-callback communicator) and with an emulated world.  Checks the range split, the block layout,
+the pieces of the sub-chunk pipeline, the reassembly and the replicated control flow: every rank must end with
+exactly the graph a single process builds."""
 import ctypes as C
 import os
 import socket
@@ -15,73 +16,71 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-class OracleEngine:
-    """engine interface of sharded.py backed by the CPU oracle (u64 ids as int64 tensors)"""
+def make_oracle_engine(rows, dim, bp, metric=0, threads=2):
+    """the oracle's phases as a phnsw_shard_engine (u64 ids, host buffers): the C++ driver of libphnsw calls back
+    into these, so the split / block layout / reassembly / control flow under test are the product's own"""
+    import oracle
+    from parallel_hnsw_amd.sharded import PythonEngine
 
-    def __init__(self, rows, dim, bp, metric=0, threads=2):
-        import torch
-        import oracle
-        self.torch, self.oracle = torch, oracle
-        self.ix = oracle.Index(rows, dim=dim, metric=metric, sum_mode=oracle.SUM_BLOCKED64)
-        self.ix.set_sum_mode(oracle.SUM_BLOCKED64)
-        self.bp, self.threads, self.device = bp, threads, "cpu"
-        self.L = oracle.lib()
+    class OracleEngine(PythonEngine):
+        id_bytes = 8
 
-    def empty(self, shape, kind):
-        return self.torch.empty(shape, dtype=self.torch.float32 if kind == "f32" else self.torch.int64)
+        def __init__(self):
+            super().__init__()
+            self.oracle = oracle
+            self.ix = oracle.Index(rows, dim=dim, metric=metric, sum_mode=oracle.SUM_BLOCKED64)
+            self.ix.set_sum_mode(oracle.SUM_BLOCKED64)
+            self.bp, self.threads = bp, threads
+            self.L = oracle.lib()
 
-    @staticmethod
-    def _p(t):
-        assert t.is_contiguous()
-        return C.c_void_p(t.data_ptr())
+        def _sp(self, sp):
+            return type(self.bp.optimization.search).from_buffer_copy(bytes(sp))
 
-    def plan(self, vids):
-        vs = self.oracle.shuffle(np.asarray(vids, dtype=np.uint64), self.bp.seed)
-        return vs, self.oracle.calculate_partitions(len(vs), self.bp.order)
+        def plan(self, vids):
+            vs = oracle.shuffle(np.asarray(vids, dtype=np.uint64), self.bp.seed)
+            return vs, oracle.calculate_partitions(len(vs), self.bp.order)
 
-    def layer_begin(self, vids, W):
-        v = np.ascontiguousarray(vids, dtype=np.uint64)
-        assert self.L.orc_layer_begin(self.ix.h, v.ctypes.data_as(C.c_void_p), len(v), W, C.byref(self.bp)) == 0
-        return True, int(self.L.orc_layer_init_stride(self.ix.h))
+        def layer_begin(self, vids, W):
+            v = np.ascontiguousarray(vids, dtype=np.uint64)
+            assert self.L.orc_layer_begin(self.ix.h, v.ctypes.data_as(C.c_void_p), len(v), W, C.byref(self.bp)) == 0
+            return True, int(self.L.orc_layer_init_stride(self.ix.h))
 
-    def layer_init_search(self, first, count, ids, d, ln):
-        assert self.L.orc_layer_init_search(self.ix.h, C.byref(self.bp), first, count, self._p(ids), self._p(d),
-                                            self._p(ln), self.threads) == 0
+        def layer_init_search(self, first, count, ids, d, ln):
+            assert self.L.orc_layer_init_search(self.ix.h, C.byref(self.bp), first, count, ids, d, ln, self.threads) == 0
 
-    def layer_seed(self, ids, d, ln, first, count, rows, rows_d):
-        assert self.L.orc_layer_seed(self.ix.h, C.byref(self.bp), self._p(ids), self._p(d), self._p(ln), first, count,
-                                     self._p(rows), self._p(rows_d), self.threads) == 0
+        def layer_seed(self, ids, d, ln, first, count, rows_, rows_d):
+            assert self.L.orc_layer_seed(self.ix.h, C.byref(self.bp), ids, d, ln, first, count, rows_, rows_d,
+                                         self.threads) == 0
 
-    def layer_finish(self, rows, rows_d):
-        assert self.L.orc_layer_finish(self.ix.h, self._p(rows), self._p(rows_d), self.threads) == 0
+        def layer_finish(self, rows_, rows_d):
+            assert self.L.orc_layer_finish(self.ix.h, rows_, rows_d, self.threads) == 0
 
-    def layer_count(self):
-        return self.ix.layer_count
+        def layer_count(self):
+            return self.ix.layer_count
 
-    def layer_nodes(self, lft):
-        return int(self.L.orc_index_layer(self.ix.h, lft).contents.node_count)
+        def layer_nodes(self, lft):
+            return int(self.L.orc_index_layer(self.ix.h, lft).contents.node_count)
 
-    def link_search(self, lft, sp, M, first, count, ids, d, ln):
-        assert self.L.orc_link_search(self.ix.h, lft, sp, M, first, count, self._p(ids), self._p(d), self._p(ln),
-                                      self.threads) == 0
+        def link_search(self, lft, sp, M, first, count, ids, d, ln):
+            assert self.L.orc_link_search(self.ix.h, lft, self._sp(sp), M, first, count, ids, d, ln, self.threads) == 0
 
-    def link_apply(self, lft, M, ids, d, ln):
-        return int(self.L.orc_link_apply(self.ix.h, lft, M, self._p(ids), self._p(d), self._p(ln), self.threads))
+        def link_apply(self, lft, M, ids, d, ln):
+            return int(self.L.orc_link_apply(self.ix.h, lft, M, ids, d, ln, self.threads))
 
-    def promote_at_layer(self, lft):
-        return self.ix.promote_at_layer(lft, self.bp, threads=self.threads) > 0
+        def discover_hits(self, lft, sp, first, count, hit):
+            assert self.L.orc_discover_hits(self.ix.h, lft, self._sp(sp), first, count, hit, self.threads) == 0
 
-    def discover_hits(self, lft, sp, first, count, hit):
-        assert self.L.orc_discover_hits(self.ix.h, lft, sp, first, count, self._p(hit), self.threads) == 0
+        def promote_from_hits(self, lft, hit):
+            return self.L.orc_promote_at_layer_hits(self.ix.h, lft, C.byref(self.bp), hit, self.threads) > 0
 
-    def promote_from_hits(self, lft, hit):
-        return self.L.orc_promote_at_layer_hits(self.ix.h, lft, C.byref(self.bp), self._p(hit), self.threads) > 0
+        def recall_hits(self, at, op, first, count):
+            hits, sel = C.c_uint64(), C.c_uint64()
+            o = type(self.bp.optimization).from_buffer_copy(bytes(op))
+            assert self.L.orc_recall_hits(self.ix.h, at, C.byref(o), first, count, C.byref(hits), C.byref(sel),
+                                          self.threads) == 0
+            return hits.value, sel.value
 
-    def recall_hits(self, at, op, first, count):
-        hits, sel = C.c_uint64(), C.c_uint64()
-        assert self.L.orc_recall_hits(self.ix.h, at, C.byref(op), first, count, C.byref(hits), C.byref(sel),
-                                      self.threads) == 0
-        return hits.value, sel.value
+    return OracleEngine()
 
 
 CASES = [
@@ -126,10 +125,11 @@ def _worker(rank, world, port, case, out_dir):
     try:
         rows = _case_rows(case)
         bp = _case_bp(case)
-        eng = OracleEngine(rows, case["dim"], bp)
+        eng = make_oracle_engine(rows, case["dim"], bp)
         comm = TorchComm()
         b = ShardedBuilder(eng, comm, shard_min=case.get("shard_min", 0))
         b.generate(np.arange(case["n"], dtype=np.uint64))
+        assert b.stats["all_gather_calls"] > 0 and b.stats["all_gather_bytes"] == comm.bytes_gathered
         layers = [eng.ix.layer(l) for l in range(eng.ix.layer_count)]
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), count=len(layers), gathered=comm.bytes_gathered,
                  **{"nodes%d" % i: l[0] for i, l in enumerate(layers)},
@@ -165,125 +165,66 @@ def test_sharded_build_equals_single_process(case, tmp_path):
             np.testing.assert_array_equal(z["nb%d" % l], nb, err_msg="rank %d layer %d" % (rank, l))
 
 
-def test_range_split_covers_everything():
+def _emulated_build(case, world, rank=0, subchunks=None, sub_min=None):
+    """the C++ driver with an emulated world (one process plays every rank in turn) over the oracle's phases"""
+    from parallel_hnsw_amd.sharded import EmulatedComm, ShardedBuilder, sharded_tuning
+    eng = make_oracle_engine(_case_rows(case), case["dim"], _case_bp(case), threads=4)
+    b = ShardedBuilder(eng, EmulatedComm(world, rank), shard_min=case.get("shard_min", 0), subchunks=subchunks,
+                       sub_min=sub_min)
+    try:
+        b.generate(np.arange(case["n"], dtype=np.uint64))
+    finally:
+        sharded_tuning(4096, 4, 8192)
+    return eng, b.stats
+
+
+@pytest.mark.parametrize("world,rank,subchunks", [(2, 0, 1), (3, 2, 4), (8, 5, 4), (5, 0, 3)])
+def test_emulated_world_equals_single_process(world, rank, subchunks):
+    """every range split (unequal tails, empty tail ranks), the block layout with several pieces per rank and
+    the reassembly copies: an emulated world of w ranks must end with the single-process graph"""
+    import oracle
+    case = dict(n=1501, dim=24, kw=dict(seed=1))
+    eng, st = _emulated_build(case, world, rank, subchunks=subchunks, sub_min=16)
+    ref = oracle.Index.generate(_case_rows(case), np.arange(case["n"]), _case_bp(case), dim=case["dim"],
+                                sum_mode=oracle.SUM_BLOCKED64, threads=4)
+    assert eng.ix.layer_count == ref.layer_count
+    for l in range(ref.layer_count):
+        nodes, nb = ref.layer(l)
+        gn, gnb = eng.ix.layer(l)
+        np.testing.assert_array_equal(gn, nodes)
+        np.testing.assert_array_equal(gnb, nb, err_msg="layer %d" % l)
+    assert st["phases"] > st["phases_whole"] >= 0
+    assert st["all_gather_calls"] + st["all_reduce_calls"] >= st["phases"] - st["phases_whole"]
+    assert st["seconds_others"] > 0 and st["seconds_sharded"] > 0
+
+
+def test_short_lists_run_whole_without_collectives():
+    """work lists below shard_min are not split: no all-gather, no all-reduce for them"""
+    case = dict(n=700, dim=16, kw=dict(order=6, neighborhood_size=6, zero_layer_neighborhood_size=12, seed=3),
+                shard_min=10 ** 6)
+    eng, st = _emulated_build(case, 4)
+    assert st["all_gather_calls"] == 0 and st["all_reduce_calls"] == 0 and st["phases"] == st["phases_whole"] > 0
+
+
+def test_driver_refuses_bad_worlds():
+    import parallel_hnsw_amd as ph
+    from parallel_hnsw_amd._lib import Comm
     from parallel_hnsw_amd.sharded import ShardedBuilder
 
-    class FakeComm:
-        def __init__(self, r, w):
-            self.rank, self.world = r, w
+    class Bad:
+        rank, world = 3, 2
 
-    class FakeEngine:
-        bp = None
+        def c_comm(self, device=0):
+            return Comm(rank=3, world=2, emulate=1)
 
-    for n in (1, 2, 7, 8, 9, 1000, 1001):
-        for w in (1, 2, 3, 8):
-            seen = []
-            for r in range(w):
-                b = ShardedBuilder(FakeEngine(), FakeComm(r, w), shard_min=0)
-                chunk, first, count = b._range(n)
-                assert count <= chunk and first + count <= n
-                assert first == min(n, r * chunk)
-                seen += list(range(first, first + count))
-            assert seen == list(range(n))
+    case = dict(n=300, dim=8, kw=dict(seed=1))
+    eng = make_oracle_engine(_case_rows(case), case["dim"], _case_bp(case))
+    with pytest.raises(ph.PhnswError):
+        ShardedBuilder(eng, Bad()).generate(np.arange(300, dtype=np.uint64))
 
+    class NoTransport(Bad):
+        def c_comm(self, device=0):
+            return Comm(rank=0, world=2, emulate=0)
 
-def test_phase_packs_pipelines_and_reassembles_exactly():
-    """ShardedBuilder._phase: each piece of a rank's range travels as one byte block (ids, distances and lengths
-    side by side), pieces are gathered asynchronously and land at their global rows -- with and without the
-    sub-chunk pipeline, for 4- and 8-byte ids"""
-    import torch
-    from parallel_hnsw_amd.sharded import ShardedBuilder
-
-    for id_dtype in (torch.int32, torch.int64):
-        for world, n, subs in ((2, 37, 1), (3, 100, 4), (2, 64, 4), (4, 1001, 4)):
-            def item(i, M):  # what work item i produces
-                return (torch.arange(M, dtype=id_dtype) + 1000 * i, torch.full((M,), float(i)) + torch.arange(M) / 16.0, i + 7)
-
-            class Comm:
-                """rank `me` of `world`: the other ranks' blocks are computed on the spot"""
-                def __init__(self, me, builder_of):
-                    self.rank, self.world, self.builder_of, self.asyncs = me, world, builder_of, 0
-
-                def all_gather(self, t):
-                    return torch.cat([self.builder_of(r).block for r in range(world)], 0)
-
-                def all_gather_async(self, t):
-                    self.asyncs += 1
-                    blocks = [self.builder_of(r).block for r in range(world)]
-
-                    class H:
-                        def wait(self_inner):
-                            return torch.cat(blocks, 0)
-                    return H()
-
-            class Engine:
-                bp = None
-
-                def empty(self, shape, kind):
-                    return torch.zeros(shape, dtype=torch.float32 if kind == "f32" else id_dtype)
-
-            M = 3
-            # every rank's packed piece depends only on (rank, piece): precompute them by running the phase's packing
-            # for each rank in turn, piece by piece, with a recording comm
-            results = {}
-            for me in range(world):
-                pieces = []
-
-                class Rec:
-                    rank, world_ = me, world
-
-                    def __init__(self):
-                        self.rank, self.world = me, world
-
-                    def all_gather(self, t):
-                        pieces.append(t.clone())
-                        return torch.cat([t] * world, 0)
-
-                    def all_gather_async(self, t):
-                        pieces.append(t.clone())
-
-                        class H:
-                            def wait(self_inner):
-                                return torch.cat([t] * world, 0)
-                        return H()
-
-                b = ShardedBuilder(Engine(), Rec(), shard_min=0)
-                b.SUBCHUNKS, b.SUB_MIN = subs, 1
-
-                def run(first, count, outs):
-                    for r in range(count):
-                        i, dd, l = item(first + r, M)
-                        outs[0][r], outs[1][r], outs[2][r] = i, dd, l
-                b._phase(n, [(M, "id"), (M, "f32"), (None, "id")], run)
-                results[me] = pieces
-            # now the real thing on rank 0 with a comm that hands out the recorded pieces in order
-            turn = [0]
-
-            class Replay:
-                def __init__(self):
-                    self.rank, self.world = 0, world
-
-                def _next(self):
-                    k = turn[0]
-                    turn[0] += 1
-                    return torch.cat([results[r][k] for r in range(world)], 0)
-
-                def all_gather(self, t):
-                    return self._next()
-
-                def all_gather_async(self, t):
-                    g = self._next()
-
-                    class H:
-                        def wait(self_inner):
-                            return g
-                    return H()
-
-            b = ShardedBuilder(Engine(), Replay(), shard_min=0)
-            b.SUBCHUNKS, b.SUB_MIN = subs, 1
-            gi, gd, gl = b._phase(n, [(M, "id"), (M, "f32"), (None, "id")], run)
-            assert gi.shape == (n, M) and gd.shape == (n, M) and gl.shape == (n,)
-            assert gi.dtype == id_dtype and gd.dtype == torch.float32 and gl.dtype == id_dtype
-            for i in range(n):
-                ei, ed, el = item(i, M)
-                assert torch.equal(gi[i], ei) and torch.equal(gd[i], ed) and int(gl[i]) == el, (world, n, subs, i)
+    with pytest.raises(ph.PhnswError):
+        ShardedBuilder(eng, NoTransport()).generate(np.arange(300, dtype=np.uint64))
