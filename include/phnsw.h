@@ -305,6 +305,9 @@ typedef struct phnsw_sharded_stats {
   uint64_t all_reduce_calls;
   uint64_t phases;           /* sharded phases run */
   uint64_t phases_whole;     /* work lists too short to split (every rank ran them whole, no collective) */
+  /* this rank's seconds by phase: the sharded ones 0 layer_init_search, 1 layer_seed, 2 link_search, 3 recall_hits,
+   * 4 discover_hits; the replicated ones 5 plan, 6 layer_begin, 7 layer_finish, 8 link_apply, 9 promote_from_hits */
+  double seconds_by_phase[10];
 } phnsw_sharded_stats;
 
 /* Hnsw::generate (lib.rs:825-893) over the ranks of `comm`; comm == NULL or world == 1 is phnsw_build.
@@ -389,6 +392,16 @@ int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, u
 int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
                                  const phnsw_build_params *centroid_bp, const phnsw_search_params *quantized_search,
                                  int centroid_metric, phnsw_store **out);
+/* Both constructors with Quantizer::quantize split over the ranks of `comm` (PQ encode shards by
+ * vector range, pq.rs:326-333): codebooks / the centroid index are computed identically on every rank, rank r
+ * encodes vectors [r*chunk, (r+1)*chunk), the code rows are all-gathered (n x m code bytes, resp. n x m x 2).
+ * comm == NULL is the single-GPU call.  Every rank passes the same store contents and parameters. */
+int phnsw_store_create_pq_sharded(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, uint32_t kmeans_iters,
+                                  uint64_t sample, const phnsw_comm *comm, phnsw_store **out);
+int phnsw_store_create_pq_shared_sharded(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
+                                         const phnsw_build_params *centroid_bp,
+                                         const phnsw_search_params *quantized_search, int centroid_metric,
+                                         const phnsw_comm *comm, phnsw_store **out);
 int phnsw_pq_shared_read(const phnsw_store *s, uint16_t *codes, float *codebook);
 int phnsw_pq_shared_reconstruct_store(const phnsw_store *s, phnsw_store **out);
 int phnsw_pq_info(const phnsw_store *s, uint32_t *m, uint32_t *ksub, uint32_t *dsub);

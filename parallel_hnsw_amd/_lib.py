@@ -56,7 +56,11 @@ class ShardedStats(C.Structure):
     _fields_ = [("seconds_total", C.c_double), ("seconds_sharded", C.c_double), ("seconds_replicated", C.c_double),
                 ("seconds_comm", C.c_double), ("seconds_others", C.c_double), ("all_gather_bytes", C.c_uint64),
                 ("all_gather_calls", C.c_uint64), ("all_reduce_calls", C.c_uint64), ("phases", C.c_uint64),
-                ("phases_whole", C.c_uint64)]
+                ("phases_whole", C.c_uint64), ("seconds_by_phase", C.c_double * 10)]
+
+
+SHARD_PHASE_NAMES = ("layer_init_search", "layer_seed", "link_search", "recall_hits", "discover_hits", "plan", "layer_begin",
+                     "layer_finish", "link_apply", "promote_from_hits")
 
 
 _vpx, _u64x, _u32x = C.c_void_p, C.c_uint64, C.c_uint32
@@ -149,6 +153,9 @@ SYMBOLS = {
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),
     "phnsw_store_create_pq_kmeans": (_i32, [_vp, _u32, _u32, _u64, _u32, _u64, _pp]),
     "phnsw_store_create_pq_shared": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(BuildParams), C.POINTER(SearchParams), _i32, _pp]),
+    "phnsw_store_create_pq_sharded": (_i32, [_vp, _u32, _u32, _u64, _u32, _u64, C.POINTER(Comm), _pp]),
+    "phnsw_store_create_pq_shared_sharded": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(BuildParams), C.POINTER(SearchParams),
+                                                    _i32, C.POINTER(Comm), _pp]),
     "phnsw_pq_shared_read": (_i32, [_vp, _vp, _vp]),
     "phnsw_pq_shared_reconstruct_store": (_i32, [_vp, _pp]),
     "phnsw_pq_info": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),

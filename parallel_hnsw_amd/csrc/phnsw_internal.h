@@ -291,6 +291,10 @@ static inline size_t ph_pq_lds_bytes(const phnsw_store *s) {
   return s->codes ? (size_t)s->pq_m * s->pq_ksub * (s->pq_table_f16 == 2 ? 1 : (s->pq_table_f16 ? 2 : 4)) : 0;
 }
 
+// sharded.hip: rank r's share of n items, and a synchronous all-gather of device blocks over any transport
+void ph_comm_range(const phnsw_comm *comm, uint32_t r, uint64_t n, uint64_t *chunk, uint64_t *first, uint64_t *count);
+int ph_comm_all_gather_device(const phnsw_comm *comm, const void *send_dev, void *recv_dev, uint64_t bytes);
+
 // misc kernels (misc.hip)
 int ph_synth_rows(float *rows_dev, uint64_t first, uint64_t count, uint32_t dim, uint32_t ld,
                   uint64_t seed, int normalize, hipStream_t s);

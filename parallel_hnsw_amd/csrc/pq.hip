@@ -174,8 +174,48 @@ __global__ __launch_bounds__(64) void ph_pq_rerank_kernel(PhDistArgs full, const
 // Codebooks: random_centroids (pq.rs:261-285) when kmeans_iters == 0, else Lloyd iterations from that
 // start over the first min(n, sample) vectors of the same shuffle (per-sub-space
 // k-means, own implementation -- the reference's linfa k-means is dead code, pq.rs:215-259).
-extern "C" int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
-                                            uint32_t kmeans_iters, uint64_t sample, phnsw_store **out) try {
+// Quantizer::quantize for every vector, split over the ranks of `comm` (pq.rs:326-333 runs it as
+// one par_iter over the vectors): rank r encodes the vector range [r*chunk, (r+1)*chunk) into its place of the
+// code array, the ranges are all-gathered (n x code bytes in all), every rank ends with the full array.  An
+// emulated world computes the ranges in turn.  `encode(first, count, dst)` writes the codes of `count` vectors.
+template <class Encode>
+static int pq_encode_sharded(const phnsw_comm *comm, uint64_t n, uint64_t row_bytes, void **codes_io, Encode &&encode) {
+  const uint32_t w = (comm && comm->world > 1) ? comm->world : 1;
+  if (w == 1) return encode((uint64_t)0, n, *codes_io);
+  if (comm->rank >= w || (!comm->all_gather && !comm->emulate)) {
+    ph_set_error("sharded PQ encode: rank %u of world %u without a transport", comm->rank, w);
+    return PHNSW_E_INVALID;
+  }
+  uint64_t chunk, first, count;
+  ph_comm_range(comm, comm->rank, n, &chunk, &first, &count);
+  // the code array is re-allocated padded to world * chunk rows so that it IS the receive buffer
+  void *padded = nullptr, *send = nullptr;
+  PH_HIP(hipMalloc(&padded, (size_t)w * chunk * row_bytes));
+  int rc = 0;
+  if (!comm->all_gather) {
+    for (uint32_t r = 0; r < w && !rc; r++) {
+      ph_comm_range(comm, r, n, &chunk, &first, &count);
+      if (count) rc = encode(first, count, (char *)padded + first * row_bytes);
+    }
+  } else {
+    hipError_t e = hipMalloc(&send, (size_t)chunk * row_bytes);
+    if (e != hipSuccess) rc = ph_hip_fail(e, "pq send block", __FILE__, __LINE__);
+    if (!rc && count) rc = encode(first, count, send);
+    if (!rc) rc = ph_comm_all_gather_device(comm, send, padded, chunk * row_bytes);
+    if (send) hipFree(send);
+  }
+  if (rc) {
+    hipFree(padded);
+    return rc;
+  }
+  hipFree(*codes_io);
+  *codes_io = padded;
+  return 0;
+}
+
+extern "C" int phnsw_store_create_pq_sharded(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
+                                             uint32_t kmeans_iters, uint64_t sample, const phnsw_comm *comm,
+                                             phnsw_store **out) try {
   if (!full || !out || full->codes || !full->rows || m == 0 || ksub == 0 || ksub > 256 || (m % 4) ||
       (full->dim % m) || ksub > full->n) {
     ph_set_error("phnsw_store_create_pq: need an f32 store, m %% 4 == 0, dim %% m == 0, 1 <= ksub <= min(256, n)");
@@ -245,12 +285,15 @@ extern "C" int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint3
     if (e != hipSuccess) rc = ph_hip_fail(e, "pq k-means", __FILE__, __LINE__);
   }
   if (!rc) {
-    uint32_t grid = (uint32_t)std::min<uint64_t>(s->n, 256u * 32u);
-    hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, full->rows, full->ld, s->n, m, ksub, dsub,
-                       s->codebook, s->codes, (uint64_t)m, (uint64_t)1);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) rc = ph_hip_fail(e, "pq encode", __FILE__, __LINE__);
+    // codebooks are replicated (computed identically on every rank from the seed); the encode is what shards
+    rc = pq_encode_sharded(comm, s->n, m, (void **)&s->codes, [&](uint64_t first, uint64_t count, void *dst) {
+      uint32_t grid = (uint32_t)std::min<uint64_t>(count, 256u * 32u);
+      hipLaunchKernelGGL(ph_pq_encode_kernel, dim3(grid), dim3(64), 0, 0, full->rows + first * full->ld, full->ld, count, m,
+                         ksub, dsub, s->codebook, (uint8_t *)dst, (uint64_t)m, (uint64_t)1);
+      hipError_t e2 = hipGetLastError();
+      if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+      return e2 == hipSuccess ? 0 : ph_hip_fail(e2, "pq encode", __FILE__, __LINE__);
+    });
   }
   if (sample_d) hipFree(sample_d);
   if (train) hipFree(train);
@@ -265,8 +308,13 @@ extern "C" int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint3
   return 0;
 } catch (...) { return ph_caught(); }
 
+extern "C" int phnsw_store_create_pq_kmeans(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed,
+                                            uint32_t kmeans_iters, uint64_t sample, phnsw_store **out) try {
+  return phnsw_store_create_pq_sharded(full, m, ksub, seed, kmeans_iters, sample, nullptr, out);
+} catch (...) { return ph_caught(); }
+
 extern "C" int phnsw_store_create_pq(phnsw_store *full, uint32_t m, uint32_t ksub, uint64_t seed, phnsw_store **out) try {
-  return phnsw_store_create_pq_kmeans(full, m, ksub, seed, 0, 0, out);
+  return phnsw_store_create_pq_sharded(full, m, ksub, seed, 0, 0, nullptr, out);
 } catch (...) { return ph_caught(); }
 
 // ------------------------------------------------------------------ the reference's quantizer shape
@@ -321,10 +369,10 @@ static int pq_shared_encode_device(const phnsw_store *s, const float *rows_dev, 
   return rc;
 }
 
-extern "C" int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
-                                            const phnsw_build_params *centroid_bp,
-                                            const phnsw_search_params *quantized_search, int centroid_metric,
-                                            phnsw_store **out) try {
+extern "C" int phnsw_store_create_pq_shared_sharded(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
+                                                    const phnsw_build_params *centroid_bp,
+                                                    const phnsw_search_params *quantized_search, int centroid_metric,
+                                                    const phnsw_comm *comm, phnsw_store **out) try {
   if (!full || !out || !full->rows || !centroid_bp || !quantized_search || dsub == 0 || (dsub % 4) || (full->dim % dsub) ||
       full->ld != full->dim || n_centroids == 0 || n_centroids > 65535 || n_centroids > full->n ||
       quantized_search->number_of_candidates == 0 || quantized_search->number_of_candidates > 1024 ||
@@ -406,15 +454,25 @@ extern "C" int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, ui
   if (e == hipSuccess) e = hipMemcpy(s->codebook, cb.data(), cb.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&s->codes16, (size_t)s->n * m * 2);
   if (e != hipSuccess) return fail(ph_hip_fail(e, "pq shared alloc", __FILE__, __LINE__));
-  // centroid_quantizer.quantize(&v) for every vector  pq.rs:326-333
-  rc = pq_shared_encode_device(s, full->rows, s->n, s->codes16);
-  if (!rc) {
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) rc = ph_hip_fail(e, "pq shared encode", __FILE__, __LINE__);
-  }
+  // centroid_quantizer.quantize(&v) for every vector  pq.rs:326-333 -- over the ranks of comm; the centroid index
+  // above is replicated (built identically on every rank: 65 535 x 16 floats at most)
+  rc = pq_encode_sharded(comm, s->n, (uint64_t)m * 2, (void **)&s->codes16, [&](uint64_t first, uint64_t count, void *dst) {
+    int r2 = pq_shared_encode_device(s, full->rows + first * full->ld, count, (uint16_t *)dst);
+    if (r2) return r2;
+    hipError_t e2 = hipDeviceSynchronize();
+    return e2 == hipSuccess ? 0 : ph_hip_fail(e2, "pq shared encode", __FILE__, __LINE__);
+  });
   if (rc) return fail(rc);
   *out = s;
   return 0;
+} catch (...) { return ph_caught(); }
+
+extern "C" int phnsw_store_create_pq_shared(phnsw_store *full, uint32_t dsub, uint32_t n_centroids, uint64_t seed,
+                                            const phnsw_build_params *centroid_bp,
+                                            const phnsw_search_params *quantized_search, int centroid_metric,
+                                            phnsw_store **out) try {
+  return phnsw_store_create_pq_shared_sharded(full, dsub, n_centroids, seed, centroid_bp, quantized_search, centroid_metric,
+                                              nullptr, out);
 } catch (...) { return ph_caught(); }
 
 extern "C" int phnsw_pq_shared_read(const phnsw_store *s, uint16_t *codes, float *codebook) try {

@@ -185,7 +185,7 @@ struct Driver {
   // One sharded phase over a list of n work items.  run(first, count, outs) fills rows [0, count) of the
   // given arrays with the results of items [first, first + count).  full[a] receives an engine buffer of
   // >= n items of array a, identical on every rank (owned by the driver until release()).
-  int phase(uint64_t n, const std::vector<Spec> &specs, const Run &run, std::vector<void *> &full) {
+  int phase(int kind, uint64_t n, const std::vector<Spec> &specs, const Run &run, std::vector<void *> &full) {
     const size_t A = specs.size();
     full.assign(A, nullptr);
     st.phases++;
@@ -199,6 +199,7 @@ struct Driver {
       int rc = run(0, n, full.data());
       // every rank repeats a whole list; it counts as this rank's share of the phase all the same
       st.seconds_sharded += now_s() - t0;
+      st.seconds_by_phase[kind] += now_s() - t0;
       return rc;
     }
     uint64_t chunk, first, count;
@@ -237,6 +238,7 @@ struct Driver {
           double t0 = now_s();
           int rc = run(first + p.lo, cnt, outs.data());
           st.seconds_sharded += now_s() - t0;
+          st.seconds_by_phase[kind] += now_s() - t0;
           if (rc) return rc;
         }
         PH_TRY(gather(p.send, p.recv, p.block));
@@ -250,6 +252,7 @@ struct Driver {
           double t0 = now_s();
           int rc = run(f2 + p.lo, cnt, outs.data());
           (r == comm.rank ? st.seconds_sharded : st.seconds_others) += now_s() - t0;
+          if (r == comm.rank) st.seconds_by_phase[kind] += now_s() - t0;
           if (rc) return rc;
         }
         st.all_gather_bytes += p.block * comm.world;
@@ -276,10 +279,11 @@ struct Driver {
   }
 
   template <class F>
-  int replicated(F &&f) {
+  int replicated(int kind, F &&f) {
     double t0 = now_s();
     int rc = f();
     st.seconds_replicated += now_s() - t0;
+    st.seconds_by_phase[kind] += now_s() - t0;
     return rc;
   }
 
@@ -287,21 +291,21 @@ struct Driver {
   int generate_layer(const uint64_t *vids, uint64_t n, uint64_t W) {
     int needs = 0;
     uint32_t K = 0;
-    PH_TRY(replicated([&] { return e->layer_begin(e->ctx, vids, n, W, &needs, &K); }));
+    PH_TRY(replicated(6, [&] { return e->layer_begin(e->ctx, vids, n, W, &needs, &K); }));
     if (!needs) return 0;
     const uint32_t ib = e->id_bytes;
     std::vector<void *> init, rows;
-    PH_TRY(phase(n, {{K, ib}, {K, 4}, {1, ib}},
+    PH_TRY(phase(0, n, {{K, ib}, {K, 4}, {1, ib}},
                  [&](uint64_t f, uint64_t c, void *const *o) {
                    return e->layer_init_search(e->ctx, f, c, o[0], (float *)o[1], o[2]);
                  },
                  init));
-    PH_TRY(phase(n, {{(uint32_t)W, ib}, {(uint32_t)W, 4}},
+    PH_TRY(phase(1, n, {{(uint32_t)W, ib}, {(uint32_t)W, 4}},
                  [&](uint64_t f, uint64_t c, void *const *o) {
                    return e->layer_seed(e->ctx, init[0], (const float *)init[1], init[2], f, c, o[0], (float *)o[1]);
                  },
                  rows));
-    PH_TRY(replicated([&] { return e->layer_finish(e->ctx, rows[0], (const float *)rows[1]); }));
+    PH_TRY(replicated(7, [&] { return e->layer_finish(e->ctx, rows[0], (const float *)rows[1]); }));
     for (void *p : init) release(p);
     for (void *p : rows) release(p);
     return 0;
@@ -312,13 +316,13 @@ struct Driver {
     const uint64_t n = e->layer_nodes(e->ctx, lft);
     const uint32_t ib = e->id_bytes;
     std::vector<void *> res;
-    PH_TRY(phase(n, {{(uint32_t)M, ib}, {(uint32_t)M, 4}, {1, ib}},
+    PH_TRY(phase(2, n, {{(uint32_t)M, ib}, {(uint32_t)M, 4}, {1, ib}},
                  [&](uint64_t f, uint64_t c, void *const *o) {
                    return e->link_search(e->ctx, lft, sp, M, f, c, o[0], (float *)o[1], o[2]);
                  },
                  res));
     uint64_t added = 0;
-    PH_TRY(replicated([&] { return e->link_apply(e->ctx, lft, M, res[0], (const float *)res[1], res[2], &added); }));
+    PH_TRY(replicated(8, [&] { return e->link_apply(e->ctx, lft, M, res[0], (const float *)res[1], res[2], &added); }));
     for (void *p : res) release(p);
     return 0;
   }
@@ -340,6 +344,7 @@ struct Driver {
       double t0 = now_s();
       PH_TRY(e->recall_hits(e->ctx, at, op, first, count, &h, &sel));
       (r == comm.rank ? st.seconds_sharded : st.seconds_others) += now_s() - t0;
+      if (r == comm.rank) st.seconds_by_phase[3] += now_s() - t0;
       if (sel != selection) {
         ph_set_error("sharded build: the engine samples %llu vectors, the driver %llu", (unsigned long long)sel,
                      (unsigned long long)selection);
@@ -386,12 +391,12 @@ struct Driver {
   int promote_at_layer(uint32_t lft, int *promoted) {
     const uint64_t n = e->layer_nodes(e->ctx, lft);
     std::vector<void *> hit;
-    PH_TRY(phase(n, {{1, e->id_bytes}},
+    PH_TRY(phase(4, n, {{1, e->id_bytes}},
                  [&](uint64_t f, uint64_t c, void *const *o) {
                    return e->discover_hits(e->ctx, lft, &bp.optimization.search, f, c, o[0]);
                  },
                  hit));
-    PH_TRY(replicated([&] { return e->promote_from_hits(e->ctx, lft, hit[0], promoted); }));
+    PH_TRY(replicated(9, [&] { return e->promote_from_hits(e->ctx, lft, hit[0], promoted); }));
     release(hit[0]);
     return 0;
   }
@@ -455,7 +460,7 @@ struct Driver {
   int generate(const uint64_t *vids, uint64_t n, phnsw_progress_cb cb, void *user) {
     std::vector<uint64_t> vs(n), sizes(PH_MAX_LAYERS + 8);
     uint32_t cnt = 0;
-    PH_TRY(replicated([&] { return e->plan(e->ctx, vids, n, vs.data(), sizes.data(), (uint32_t)sizes.size(), &cnt); }));
+    PH_TRY(replicated(5, [&] { return e->plan(e->ctx, vids, n, vs.data(), sizes.data(), (uint32_t)sizes.size(), &cnt); }));
     sizes.resize(cnt);
     size_t i = 0;
     while (i != sizes.size()) {  // lib.rs:854-890
@@ -599,6 +604,48 @@ bool engine_complete(const phnsw_shard_engine *e) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------ shared with pq.hip (sharded encode)
+
+// rank r's share of n items under `comm` (every list is split, however short: callers decide)
+void ph_comm_range(const phnsw_comm *comm, uint32_t r, uint64_t n, uint64_t *chunk, uint64_t *first, uint64_t *count) {
+  const uint32_t w = comm ? std::max<uint32_t>(comm->world, 1) : 1;
+  const uint64_t c = (n + w - 1) / w, f = std::min<uint64_t>(n, (uint64_t)r * c);
+  *chunk = c, *first = f, *count = std::min<uint64_t>(n, f + c) - f;
+}
+
+// synchronous all-gather of device blocks through any transport of phnsw_comm (not for emulated worlds)
+int ph_comm_all_gather_device(const phnsw_comm *comm, const void *send_dev, void *recv_dev, uint64_t bytes) {
+  if (!comm || !comm->all_gather) {
+    ph_set_error("all_gather: no transport");
+    return PHNSW_E_INVALID;
+  }
+  int rc = 0;
+  if (comm->host_buffers) {
+    void *hs = nullptr, *hr = nullptr;
+    PH_HIP(hipHostMalloc(&hs, bytes, hipHostMallocDefault));
+    hipError_t e = hipHostMalloc(&hr, bytes * comm->world, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemcpy(hs, send_dev, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) rc = comm->all_gather(comm->ctx, hs, hr, bytes, nullptr);
+    if (e == hipSuccess && !rc) e = hipMemcpy(recv_dev, hr, bytes * comm->world, hipMemcpyHostToDevice);
+    hipHostFree(hs);
+    if (hr) hipHostFree(hr);
+    if (e != hipSuccess) return ph_hip_fail(e, "all_gather staging", __FILE__, __LINE__);
+  } else {
+    hipStream_t st = nullptr;
+    PH_HIP(hipDeviceSynchronize());
+    PH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    rc = comm->all_gather(comm->ctx, send_dev, recv_dev, bytes, st);
+    hipError_t e = hipStreamSynchronize(st);
+    hipStreamDestroy(st);
+    if (e != hipSuccess) return ph_hip_fail(e, "all_gather", __FILE__, __LINE__);
+  }
+  if (rc > 0) {
+    ph_set_error("all_gather failed with %d", rc);
+    return PHNSW_E_INVALID;
+  }
+  return rc;
+}
 
 // ------------------------------------------------------------------ C ABI
 

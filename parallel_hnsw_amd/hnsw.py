@@ -154,11 +154,14 @@ class PqStore(VectorStore):
 
     TABLE_MODES = {"f32": 0, "f16": 1, "u8": 2}
 
-    def __init__(self, full, m, ksub=256, seed=0, table_f16=False, table_mode=None, kmeans_iters=0, kmeans_sample=0):
+    def __init__(self, full, m, ksub=256, seed=0, table_f16=False, table_mode=None, kmeans_iters=0, kmeans_sample=0,
+                 comm=None):
         """table_mode: "f32" (reference arithmetic), "f16" or "u8" (phnsw_pq_set_table_mode); kmeans_iters: Lloyd
-        iterations on the codebooks (0 = the reference's random_centroids, pq.rs:261-285)"""
+        iterations on the codebooks (0 = the reference's random_centroids, pq.rs:261-285); comm: a communicator of
+        parallel_hnsw_amd.sharded -- the encode of pq.rs:326-333 split over its ranks, codes all-gathered"""
         h = C.c_void_p()
-        check(lib().phnsw_store_create_pq_kmeans(full._h, m, ksub, seed, kmeans_iters, kmeans_sample, C.byref(h)))
+        cc = C.byref(comm.c_comm(full.device)) if comm is not None else None
+        check(lib().phnsw_store_create_pq_sharded(full._h, m, ksub, seed, kmeans_iters, kmeans_sample, cc, C.byref(h)))
         VectorStore.__init__(self, _handle=h, device=full.device)
         mode = self.TABLE_MODES[table_mode] if table_mode is not None else int(table_f16)
         if mode:
@@ -209,12 +212,13 @@ class SharedPqStore(VectorStore):
     sub-vectors shared by all sub-spaces, u16 codes, quantize = top-1 of an HNSW search over the centroids"""
 
     def __init__(self, full, centroid_size, number_of_centroids, seed=0, centroid_bp=None, quantized_search=None,
-                 centroid_metric=METRIC_L2):
+                 centroid_metric=METRIC_L2, comm=None):
         h = C.c_void_p()
         cbp = centroid_bp or BuildParameters()
         qs = quantized_search or SearchParameters()
-        check(lib().phnsw_store_create_pq_shared(full._h, centroid_size, number_of_centroids, seed, C.byref(cbp), C.byref(qs),
-                                                 centroid_metric, C.byref(h)))
+        cc = C.byref(comm.c_comm(full.device)) if comm is not None else None
+        check(lib().phnsw_store_create_pq_shared_sharded(full._h, centroid_size, number_of_centroids, seed, C.byref(cbp),
+                                                         C.byref(qs), centroid_metric, cc, C.byref(h)))
         VectorStore.__init__(self, _handle=h, device=full.device)
         self.full = full
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()

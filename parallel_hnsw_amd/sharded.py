@@ -18,12 +18,14 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (AllGatherFn, AllReduceFn, BuildParams, Comm, OptimizationParams, SearchParams, ShardEngine,
-                   ShardedStats, check, lib)
+                   ShardedStats, SHARD_PHASE_NAMES, check, lib)
 from .hnsw import BuildParameters, Hnsw
 
 
 def _stats_dict(st):
-    return {k: getattr(st, k) for k, _ in ShardedStats._fields_}
+    d = {k: getattr(st, k) for k, _ in ShardedStats._fields_ if k != "seconds_by_phase"}
+    d["seconds_by_phase"] = {name: st.seconds_by_phase[i] for i, name in enumerate(SHARD_PHASE_NAMES)}
+    return d
 
 
 class _CommBase:

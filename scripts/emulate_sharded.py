@@ -59,7 +59,8 @@ for w in [int(x) for x in os.environ.get("EMU_WORLDS", "1,2,4,8").split(",")]:
                  "host_collective_s": round(host, 4), "all_gather_gb_per_rank": round(st["all_gather_bytes"] / 1e9, 3),
                  "collectives": st["all_gather_calls"] + st["all_reduce_calls"], "phases": st["phases"],
                  "phases_not_split": st["phases_whole"], "others_s": round(st["seconds_others"], 2),
-                 "bottom_layer_identical_to_phnsw_build": same})
+                 "bottom_layer_identical_to_phnsw_build": same,
+                 "rank0_seconds_by_phase": {k: round(v, 3) for k, v in st["seconds_by_phase"].items()}})
     print(json.dumps(rows[-1]), flush=True)
     del h
 print(json.dumps({"n": n, "dim": dim, "dataset": kind, "single_gpu_s": round(single, 3), "link_gbs": link_gbs,

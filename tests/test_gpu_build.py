@@ -213,7 +213,9 @@ def _two_rank_worker(rank, world, port, out_dir):
         b = ph.ShardedBuilder(eng, comm, shard_min=256)  # split all but the tiny layers
         h = b.generate(np.arange(n))
         assert b.stats["all_gather_bytes"] == comm.bytes_gathered - before > 0
-        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered,
+        # PQ encode over the same two ranks: each encodes half the vectors, codes all-gathered
+        pq = ph.PqStore(store, 16, 64, 3, comm=comm)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), gathered=comm.bytes_gathered, codes=pq.codes(),
                  **{"nb%d" % l: h._layer(l).neighbors for l in range(h.layer_count())})
     finally:
         dist.destroy_process_group()
@@ -232,11 +234,13 @@ def test_two_ranks_one_gpu_rehearsal(tmp_path):
     n, dim = 3000, 64
     store = ph.VectorStore.synthetic(n, dim, seed=42)
     ref = ph.Hnsw.generate(store, np.arange(n), ph.BuildParameters(seed=6))
+    codes = ph.PqStore(store, 16, 64, 3).codes()
     for r in range(2):
         z = np.load(str(tmp_path / ("r%d.npz" % r)))
         assert int(z["gathered"]) > 0
         for l in range(ref.layer_count()):
             np.testing.assert_array_equal(z["nb%d" % l], ref._layer(l).neighbors, err_msg="rank %d layer %d" % (r, l))
+        np.testing.assert_array_equal(z["codes"], codes)
 
 
 def _dup_rows(points=40, copies=60, dim=16):

@@ -321,3 +321,27 @@ def test_reference_shaped_quantizer():
     with pytest.raises(ph.PhnswError) as e:
         qh.hnsw.improve_neighbors_upto(qh.hnsw.layer_count(), ph.BuildParameters(promote=0, seed=1))
     assert e.value.code == -7
+
+
+@pytest.mark.parametrize("world,rank", [(2, 1), (3, 0), (8, 7)])
+def test_sharded_encode_equals_single_gpu_encode(world, rank):
+    """SURVEY 8e row 3 (pq.rs:326-333: the encode is one independent job per vector): both quantizers with the
+    encode split over an emulated world -- every rank's vector range encoded by its own launches into its block of
+    the (padded) code array -- give the codes of the single-GPU call and of the oracle, including ranges that do not
+    divide n and an empty tail rank"""
+    n, dim, m, ksub = 3001, 96, 24, 64
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=5)
+    comm = ph.EmulatedComm(world, rank)
+    spq = ph.PqStore(full, m, ksub, 5, comm=comm)
+    np.testing.assert_array_equal(spq.codes(), ocodes)
+    np.testing.assert_array_equal(spq.codebook().view(np.uint32), ocb.view(np.uint32))
+    spk = ph.PqStore(full, m, ksub, 5, kmeans_iters=2, kmeans_sample=1000, comm=comm)
+    ref = ph.PqStore(full, m, ksub, 5, kmeans_iters=2, kmeans_sample=1000)
+    np.testing.assert_array_equal(spk.codes(), ref.codes())
+    # the reference's own shape: shared codebook, u16 codes through the HNSW over the centroids
+    f2 = ph.VectorStore(rows[:, :dim], metric=ph.METRIC_L2)
+    kw = dict(centroid_bp=ph.BuildParameters(seed=2), quantized_search=ph.SearchParameters(32, 32, 2))
+    a = ph.SharedPqStore(f2, 16, 300, seed=3, **kw)
+    b = ph.SharedPqStore(f2, 16, 300, seed=3, comm=comm, **kw)
+    np.testing.assert_array_equal(a.codes(), b.codes())
+    np.testing.assert_array_equal(a.codebook().view(np.uint32), b.codebook().view(np.uint32))
