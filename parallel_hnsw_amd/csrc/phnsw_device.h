@@ -545,14 +545,20 @@ struct DistPQR {
   static constexpr bool GLOBAL_TABLE = true;
   static constexpr bool EARLY = true;
   uint32_t T[M];
-  uint32_t cw[M / 4];
+  uint4 cw[M / 16];  // the candidate's code row: M bytes = M/16 16-byte loads (rows are 16-byte aligned: M % 32 == 0)
   float bias, scale;
   __device__ __forceinline__ void load_table(DistPQT<true> &b, uint32_t lane) {
     bias = b.bias;
     scale = b.scale;
-    const uint32_t *t32 = (const uint32_t *)b.T;
+    // The slot is the same for every query of this wave, so its M row addresses are loop invariants: hoisted out of
+    // the query loop they cost 2 registers each and the kernel spilled 168 of them to scratch at M = 96.  The base is
+    // made opaque per query (a wave-uniform SGPR pair), the rows are reached through immediate offsets.
+    uint64_t base = (uint64_t)b.T;
+    uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    asm volatile("" : "+s"(blo), "+s"(bhi));
+    const uint32_t *t32 = (const uint32_t *)(((uint64_t)bhi << 32) | blo) + lane;
 #pragma unroll
-    for (int j = 0; j < M; j++) T[j] = t32[j * 64 + lane];
+    for (int j = 0; j < M; j++) T[j] = t32[j * 64];
   }
   __device__ __forceinline__ void prepare_raw(const PhDistArgs &d, const float *q, float *slot, uint32_t lane) {
     DistPQT<true> b;
@@ -566,20 +572,31 @@ struct DistPQR {
   }
   // request the code row of the candidate in this lane (valid lanes only)
   __device__ __forceinline__ void prefetch(const PhDistArgs &d, bool valid, uint32_t vid, uint32_t) {
-    const uint32_t *row = (const uint32_t *)(d.codes + (uint64_t)(valid ? vid : 0u) * M);
+    const uint4 *row = (const uint4 *)(d.codes + (uint64_t)(valid ? vid : 0u) * M);
 #pragma unroll
-    for (int w = 0; w < M / 4; w++) cw[w] = row[w];
+    for (int w = 0; w < M / 16; w++) cw[w] = row[w];
   }
+  // One lookup = the entry's dword from lane code >> 2 of row register j (ds_bpermute: the hardware takes
+  // (address / 4) mod 64, so the shifted code word serves as the address without masking) and its byte code & 3
+  // (v_bfe_u32 reads the low five bits of its offset operand).  Four VALU instructions and one crossbar pass per
+  // lookup; the sum is an exact integer, whatever the order.
   __device__ __forceinline__ float finish(const PhDistArgs &d, uint64_t mask, uint32_t lane) const {
     uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-      const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c & 0xFCu), (int)T[j]);
-      sum += (t >> ((c & 3u) * 8u)) & 0xFFu;
+    for (int w = 0; w < M / 4; w++) {
+      const uint4 q4 = cw[w >> 2];
+      const uint32_t c4 = (w & 3) == 0 ? q4.x : ((w & 3) == 1 ? q4.y : ((w & 3) == 2 ? q4.z : q4.w));
+      const uint32_t e4 = c4 & 0x03030303u;  // byte i: index of the entry inside its dword
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t addr = i ? (c4 >> (8 * i)) : c4;
+        const uint32_t sh = i ? (e4 >> (8 * i - 3)) : (e4 << 3);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)T[4 * w + i]);
+        sum += __builtin_amdgcn_ubfe(t, sh, 8u);
+      }
       // eight lookups in flight are enough to cover the crossbar's latency; without the fence the
       // scheduler hoists all M of them and spills the table
-      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      if ((w & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
     float r = __fadd_rn(bias, __fmul_rn(scale, (float)sum));  // exact integer sum, two roundings
     return ((mask >> lane) & 1ull) ? finalize_metric(r, d.metric) : 0.f;
