@@ -247,7 +247,7 @@ class QuantizedHnsw:
 
     @classmethod
     def reference_shaped(cls, number_of_centroids, comparator, centroid_size, bp=None, centroid_bp=None,
-                         quantized_search=None, seed=0, centroid_metric=METRIC_L2):
+                         quantized_search=None, seed=0, centroid_metric=METRIC_L2, improve_neighbors=False):
         """QuantizedHnsw::new(number_of_centroids, comparator, PqBuildParameters{centroids, hnsw, quantized_search})
         pq.rs:287-344 in its own shape: shared codebook, HNSW quantizer, u16 codes, Hnsw over the quantised
         vectors (built on their materialised reconstructions -- identical distance bits -- and adopted over
@@ -258,6 +258,11 @@ class QuantizedHnsw:
                                    centroid_metric)
         rec = self.store.reconstruct_store()
         g = Hnsw.generate(rec, np.arange(comparator.n, dtype=np.uint64), bp or BuildParameters(promote=0))
+        # QuantizedHnsw::improve_neighbors (pq.rs:372-380, what test_pq_recall asserts on): run on the graph over
+        # the reconstructions before it is adopted over the codes (same distance bits; the code rows themselves
+        # are searched, not built on)
+        self.improve_neighbors_recall = (g.improve_neighbors_upto(g.layer_count(), g.build_parameters, None)
+                                         if improve_neighbors else None)
         self.hnsw = Hnsw.from_layers(self.store, [(l.nodes, l.neighbors) for l in g.layers], g.build_parameters)
         del g, rec
         return self

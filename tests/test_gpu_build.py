@@ -136,6 +136,34 @@ def test_toy_index_properties():
         layers_equal(h, oix)
 
 
+def test_generation_rows_recorded_by_the_reference():
+    """test_generation (lib.rs:2090-2151) on the GPU: for the shuffles with which the oracle reproduces the seven
+    brute-force-consistent rows of the reference's literal, the GPU build gives them too (and the whole graph is
+    the oracle's); the exact neighbours behind them come out of the brute-force kernel in the same order"""
+    g = TOY["test_generation"]
+    lit, rows = np.array(g["neighbors"]), g["brute_force_consistent_rows"]
+    b = TOY["vectors"]["build"]
+    data = toy_vectors()
+    store = ph.VectorStore(data, metric=ph.METRIC_ONE_MINUS_DOT)
+    hit = 0
+    for seed in range(16):
+        obp_ = oracle.default_build_params(order=b["order"], neighborhood_size=3, zero_layer_neighborhood_size=6, seed=seed)
+        oix = oracle.Index.generate(data, list(range(9)), obp_, metric=oracle.METRIC_ONE_MINUS_DOT, threads=1)
+        onb = oix.layer(oix.layer_count - 1)[1].astype(np.int64)
+        if not all((onb[i] == lit[i]).all() for i in rows):
+            continue
+        hit += 1
+        h = ph.Hnsw.generate(store, np.arange(9), gbp(order=b["order"], neighborhood_size=3, zero_layer_neighborhood_size=6,
+                                                     seed=seed))
+        gnb = h.get_layer(0).neighbors.astype(np.int64)
+        for i in rows:
+            assert gnb[i].tolist() == lit[i].tolist(), (seed, i)
+    assert hit >= 1
+    ids, d = store.bruteforce_topk(data, 7)
+    for i in rows:
+        assert [int(x) for x in ids[i] if int(x) != i][:6] == lit[i].tolist(), i
+
+
 def test_build_rejects_bad_input():
     data = toy_vectors()
     store = ph.VectorStore(data, metric=ph.METRIC_ONE_MINUS_DOT)

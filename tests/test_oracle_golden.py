@@ -110,6 +110,29 @@ def test_search_finds_self(seed):
         assert i in lead
 
 
+def test_generation_rows_recorded_by_the_reference():
+    """test_generation (lib.rs:2090-2151): seven of the nine bottom-layer rows the reference recorded are the exact
+    six nearest neighbours in (distance, id) order -- they pin the metric (1 - dot, sequential f32), the ordering and
+    the tie-break of a built row (four of them hold equal distances: ids decide).  The oracle's exact k-NN must give
+    those rows literally, and its own generate must reproduce all seven for a shuffle that lets every node discover
+    its neighbourhood (which nodes meet is shuffle-dependent: thread_rng in the reference, lib.rs:832)."""
+    g = TOY["test_generation"]
+    lit, rows = np.array(g["neighbors"]), g["brute_force_consistent_rows"]
+    data = toy_vectors()
+    ix = oracle.Index(data, metric=oracle.METRIC_ONE_MINUS_DOT, sum_mode=oracle.SUM_SEQ)
+    ids, d = ix.bruteforce(data, 7, threads=1)  # self first (distance <= everything), then the six neighbours
+    for i in rows:
+        got = [int(x) for x in ids[i] if int(x) != i][:6]
+        assert got == lit[i].tolist(), i
+    assert any((d[i, 1:-1] == d[i, 2:]).any() for i in rows)  # ties are really exercised
+    reproduced = []
+    for seed in range(16):
+        built, _ = make_simple_hnsw(seed=seed)
+        nb = built.layer(built.layer_count - 1)[1].astype(np.int64)
+        reproduced.append(all((nb[i] == lit[i]).all() for i in rows))
+    assert any(reproduced), "no shuffle reproduces the seven recorded rows"
+
+
 @pytest.mark.parametrize("entry", range(9))
 def test_knn(entry):
     ix = fixture_hnsw(entry)
