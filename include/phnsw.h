@@ -186,6 +186,18 @@ int phnsw_search_batch_stored(const phnsw_index *ix, const uint64_t *qids, uint6
                               const phnsw_search_params *sp, uint32_t upto_layers,
                               const uint64_t *exclude, uint64_t *out_ids, float *out_d,
                               uint64_t *out_len, uint64_t *out_stats);
+/* the same keeping only the best k <= number_of_candidates results per query, out_* [nq][k]: the reference
+ * returns the whole queue and its callers truncate (lib.rs:1118 takes neighborhood_size, a k-NN service takes k);
+ * here the truncation happens on the device, before the transfer.  Exactly one of queries / qids is non-NULL. */
+int phnsw_search_batch_topk(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,
+                            const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude, uint64_t k,
+                            uint64_t *out_ids, float *out_d, uint64_t *out_len);
+/* Hnsw::search_instrumented  src/lib.rs:667-673: the results of phnsw_search_batch plus, per query, the second
+ * value of search_layers_instrumented (src/search.rs:93-140): the index_sum of the last hop of the bottom layer's
+ * closest_nodes that changed the best candidate (lib.rs:211-231); UINT64_MAX = usize::MAX.  f32 stores. */
+int phnsw_search_instrumented(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,
+                              const phnsw_search_params *sp, uint64_t *out_ids, float *out_d, uint64_t *out_len,
+                              uint64_t *out_index_distance);
 /* zero-copy form: everything already resident in HBM, u32 ids (0xFFFFFFFF = empty),
  * queries [nq][ldq] with ldq a multiple of 4 and zero padding, launched on `stream`
  * (a hipStream_t, NULL = default) without synchronising.  out_stats_dev [nq][2] u32.

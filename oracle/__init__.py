@@ -423,6 +423,30 @@ class Index:
             raise RuntimeError("orc_search_batch rc=%d" % rc)
         return (ids, d, ln, st) if stats else (ids, d, ln)
 
+    def search_instrumented(self, queries=None, qids=None, sp=(300, 300, 2), threads=8):
+        """batched Hnsw::search_instrumented (lib.rs:667-673) -> ids, d, len, index_distance"""
+        sp = SearchParams(*sp)
+        if queries is not None:
+            q, _, ldq = pad_rows(np.atleast_2d(queries))
+            nq, qi = q.shape[0], None
+        else:
+            q, ldq = None, 0
+            qi = np.array(qids, dtype=np.uint64)
+            nq = len(qi)
+        cap = sp.number_of_candidates
+        ids = np.empty((nq, cap), dtype=np.uint64)
+        d = np.empty((nq, cap), dtype=np.float32)
+        ln = np.zeros(nq, dtype=np.uint64)
+        idx = np.zeros(nq, dtype=np.uint64)
+        f = lib().orc_search_batch_instrumented
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, SearchParams, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_int]
+        rc = f(self.h, _p(q), ldq, _p(qi), nq, sp, _p(ids), _p(d), _p(ln), _p(idx), threads)
+        if rc:
+            raise RuntimeError("orc_search_batch_instrumented rc=%d" % rc)
+        return ids, d, ln, idx
+
     def knn(self, k, probe_depth, threads=8):
         n = self.layer(self.layer_count - 1)[0].shape[0]
         ids = np.empty((n, k), dtype=np.uint64)

@@ -139,6 +139,11 @@ int orc_search_batch(const orc_index *ix, const float *queries, uint32_t ldq,
                      const uint64_t *exclude, uint64_t *out_ids, float *out_d, uint64_t *out_len,
                      orc_stats *st, int threads);
 
+/* Hnsw::search_instrumented lib.rs:667-673: results + index_distance per query */
+int orc_search_batch_instrumented(const orc_index *ix, const float *queries, uint32_t ldq, const uint64_t *qids,
+                                  uint64_t nq, orc_search_params sp, uint64_t *out_ids, float *out_d,
+                                  uint64_t *out_len, uint64_t *out_index_distance, int threads);
+
 /* Hnsw::knn lib.rs:905-928 ; out_[ids|d] sized node_count*k, out_len per node */
 int orc_knn(const orc_index *ix, uint64_t k, uint64_t probe_depth, uint64_t *out_ids,
             float *out_d, uint64_t *out_len, int threads);

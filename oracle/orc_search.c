@@ -343,6 +343,31 @@ int orc_search(const orc_index *ix, const float *query, uint64_t qid, orc_search
   return rc;
 }
 
+/* Hnsw::search_instrumented  src/lib.rs:667-673 for a batch: the second return value of
+ * search_layers_instrumented (src/search.rs:93-140) -- the index_sum of the last hop of the bottom layer's
+ * closest_nodes that changed the best candidate (src/lib.rs:211-231) -- lands in out_index_distance[q] */
+int orc_search_batch_instrumented(const orc_index *ix, const float *queries, uint32_t ldq, const uint64_t *qids,
+                                  uint64_t nq, orc_search_params sp, uint64_t *out_ids, float *out_d,
+                                  uint64_t *out_len, uint64_t *out_index_distance, int threads) {
+  int rc_all = 0;
+  uint64_t cap = sp.number_of_candidates;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+    orc_scratch *sc = orc_scratch_new(ix, 0);
+#pragma omp for schedule(dynamic, 8)
+    for (uint64_t q = 0; q < nq; q++) {
+      int rc = orc_search_sc(ix, queries ? queries + q * (uint64_t)ldq : NULL, qids ? qids[q] : 0, sp, 0, ORC_EMPTY,
+                             out_ids + q * cap, out_d + q * cap, out_len + q, NULL, sc, out_index_distance + q);
+      if (rc) {
+#pragma omp critical
+        rc_all = rc;
+      }
+    }
+    orc_scratch_free(sc);
+  }
+  return rc_all;
+}
+
 int orc_search_batch(const orc_index *ix, const float *queries, uint32_t ldq, const uint64_t *qids,
                      uint64_t nq, orc_search_params sp, const uint64_t *exclude, uint64_t *out_ids,
                      float *out_d, uint64_t *out_len, orc_stats *st, int threads) {

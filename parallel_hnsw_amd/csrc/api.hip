@@ -540,6 +540,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   ph_pending_free(ix);
   ph_workspace_free(ix->ws[0]);
   ph_workspace_free(ix->ws[1]);
+  ph_host_stages_free(ix);
   if (ix->totals) hipFree(ix->totals);
   phnsw_store_destroy(ix->store);
   delete ix;
@@ -630,7 +631,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
-                     uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps, const uint32_t *order) {
+                     uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps, const uint32_t *order,
+                     uint32_t *out_index) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -651,6 +653,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   a.first_node = first_node;
   a.hit_eps = hit_eps;
   a.cap_max = knn_mode == 2 ? out_stride : 0;
+  a.out_index = out_index;  // Hnsw::search_instrumented: the INSTR kernels, every layer on the per-hop path, one launch
   a.order = (ix->dbg_order && ix->dbg_order_n == nq) ? ix->dbg_order : order;
   std::lock_guard<std::mutex> g(mix->ws_mutex);
   if (!mix->totals) {
@@ -671,7 +674,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   // the running candidates are parked in the output rows.
   // (layers evaluated densely, tiny.hip, never read a vector row during the traversal: they stay in
   // the first launch whatever their size)
-  const uint32_t T = knn_mode ? 0u : ph_tiny_layer_count(ix, a.n_layers, a.ef);
+  const uint32_t T = (knn_mode || out_index) ? 0u : ph_tiny_layer_count(ix, a.n_layers, a.ef);
   uint32_t first_big = a.n_layers;
   for (uint32_t l = std::max(1u, T); l < a.n_layers; l++)
     if (ph_layer_own_launch(ix->layers[l].n_nodes, ix->store->ld)) {
@@ -687,7 +690,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   }
   // (not for PQ stores: their searches are not bound by where rows come from, and every launch
   // would build the per-query table again)
-  const bool split = ix->store->rows && !a.order && !knn_mode && !out_stride && first_big < a.n_layers &&
+  const bool split = ix->store->rows && !a.order && !knn_mode && !out_stride && !out_index && first_big < a.n_layers &&
                      nq >= PH_TWO_LAUNCH_MIN &&
                      !getenv("PHNSW_NO_LOCALITY");
   if (split) {
@@ -908,149 +911,16 @@ extern "C" int phnsw_dense_top_layers(const phnsw_index *ix, uint64_t number_of_
   return 0;
 } catch (...) { return ph_caught(); }
 
-// host-pointer search: stage, launch, grow the spill workspace and retry the few queries
-// that overflowed it, convert u32 -> u64 ids
+// host-pointer searches live in hostpath.hip (persistent staging, pipelined chunks)
+int ph_search_host(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,
+                   const phnsw_search_params *sp, uint32_t upto, const uint64_t *exclude, uint64_t out_k,
+                   uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats, uint32_t knn_mode,
+                   uint64_t *out_index);
 static int search_host(const phnsw_index *ix, const float *queries, const uint64_t *qids, uint64_t nq,
                        const phnsw_search_params *sp, uint32_t upto, const uint64_t *exclude, uint64_t *out_ids,
                        float *out_d, uint64_t *out_len, uint64_t *out_stats, uint32_t knn_mode) {
-  int rc = check_sp(ix, sp);
-  if (rc) return rc;
-  if ((!queries && !qids && !knn_mode) || !out_ids || !out_d || !out_len || nq > 0xFFFFFFFFull) {
-    ph_set_error("search: invalid argument");
-    return PHNSW_E_INVALID;
-  }
-  if (nq == 0) return 0;
-  const phnsw_store *s = ix->store;
-  PH_HIP(hipSetDevice(s->device));
-  const uint32_t ef = (uint32_t)sp->number_of_candidates;
-  float *qd = nullptr, *od = nullptr;
-  uint32_t *qidd = nullptr, *exd = nullptr, *oid = nullptr, *old_ = nullptr, *ost = nullptr, *std_ = nullptr;
-  hipError_t e = hipSuccess;
-  auto cleanup = [&]() {
-    if (qd) hipFree(qd);
-    if (od) hipFree(od);
-    if (qidd) hipFree(qidd);
-    if (exd) hipFree(exd);
-    if (oid) hipFree(oid);
-    if (old_) hipFree(old_);
-    if (ost) hipFree(ost);
-    if (std_) hipFree(std_);
-  };
-  if (queries) {
-    e = hipMalloc(&qd, (size_t)nq * s->ld * 4);
-    if (e == hipSuccess && s->ld != s->dim) e = hipMemset(qd, 0, (size_t)nq * s->ld * 4);
-    if (e == hipSuccess)
-      e = hipMemcpy2D(qd, (size_t)s->ld * 4, queries, (size_t)s->dim * 4, (size_t)s->dim * 4, nq, hipMemcpyHostToDevice);
-  } else if (qids) {
-    std::vector<uint32_t> t(nq);
-    for (uint64_t i = 0; i < nq; i++) {
-      if (qids[i] >= s->n) {
-        ph_set_error("search: stored query id %llu out of range", (unsigned long long)qids[i]);
-        return PHNSW_E_INVALID;
-      }
-      t[i] = (uint32_t)qids[i];
-    }
-    e = hipMalloc(&qidd, nq * 4);
-    if (e == hipSuccess) e = hipMemcpy(qidd, t.data(), nq * 4, hipMemcpyHostToDevice);
-  }
-  if (e == hipSuccess && exclude) {
-    std::vector<uint32_t> t(nq);
-    for (uint64_t i = 0; i < nq; i++) t[i] = exclude[i] >= s->n ? PH_EMPTY32 : (uint32_t)exclude[i];
-    e = hipMalloc(&exd, nq * 4);
-    if (e == hipSuccess) e = hipMemcpy(exd, t.data(), nq * 4, hipMemcpyHostToDevice);
-  }
-  if (e == hipSuccess) e = hipMalloc(&oid, (size_t)nq * ef * 4);
-  if (e == hipSuccess) e = hipMalloc(&od, (size_t)nq * ef * 4);
-  if (e == hipSuccess) e = hipMalloc(&old_, nq * 4);
-  if (e == hipSuccess) e = hipMalloc(&ost, nq * 8);
-  if (e == hipSuccess) e = hipMalloc(&std_, nq * 4);
-  if (e != hipSuccess) {
-    cleanup();
-    return ph_hip_fail(e, "search staging", __FILE__, __LINE__);
-  }
-  uint32_t ovf_cap = default_ovf_cap(ef);
-  rc = ph_search_device(ix, qd, s->ld, qidd, nq, sp, upto, exd, oid, od, old_, ost, std_, ovf_cap, knn_mode, 0);
-  std::vector<uint32_t> h_ids((size_t)nq * ef), h_len(nq), h_st(nq * 2), h_status(nq);
-  std::vector<float> h_d((size_t)nq * ef);
-  if (!rc) {
-    e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(h_ids.data(), oid, h_ids.size() * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(h_d.data(), od, h_d.size() * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(h_len.data(), old_, nq * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(h_st.data(), ost, nq * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(h_status.data(), std_, nq * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = ph_hip_fail(e, "search readback", __FILE__, __LINE__);
-  }
-  // queries whose frontier spill outgrew the workspace: rerun them alone with 8x the room
-  for (int attempt = 0; !rc && attempt < 4; attempt++) {
-    std::vector<uint32_t> redo;
-    for (uint64_t i = 0; i < nq; i++) {
-      if (h_status[i] == 4) {
-        ph_set_error("search: a candidate vector is missing from a lower layer (layers not nested, lib.rs:261)");
-        rc = PHNSW_E_MISSING_NODE;
-        break;
-      }
-      if (h_status[i] == 5) redo.push_back((uint32_t)i);
-    }
-    if (rc || redo.empty()) break;
-    if (attempt == 3) {
-      ph_set_error("search: frontier spill exceeded %u entries for %zu queries", ovf_cap, redo.size());
-      rc = PHNSW_E_OVERFLOW;
-      break;
-    }
-    if (knn_mode) {
-      ph_set_error("knn: frontier spill exceeded %u entries", ovf_cap);
-      rc = PHNSW_E_OVERFLOW;
-      break;
-    }
-    ovf_cap *= 8;
-    for (uint32_t qi : redo) {
-      // one query per launch keeps this rare path simple
-      rc = ph_search_device(ix, qd ? qd + (size_t)qi * s->ld : nullptr, s->ld, qidd ? qidd + qi : nullptr, 1, sp, upto,
-                            exd ? exd + qi : nullptr, oid + (size_t)qi * ef, od + (size_t)qi * ef, old_ + qi,
-                            ost + 2 * (size_t)qi, std_ + qi, ovf_cap, 0, 0);
-      if (rc) break;
-      e = hipDeviceSynchronize();
-      if (e == hipSuccess) e = hipMemcpy(&h_ids[(size_t)qi * ef], oid + (size_t)qi * ef, ef * 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(&h_d[(size_t)qi * ef], od + (size_t)qi * ef, ef * 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(&h_len[qi], old_ + qi, 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(&h_st[2 * (size_t)qi], ost + 2 * (size_t)qi, 8, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(&h_status[qi], std_ + qi, 4, hipMemcpyDeviceToHost);
-      if (e != hipSuccess) {
-        rc = ph_hip_fail(e, "search retry readback", __FILE__, __LINE__);
-        break;
-      }
-    }
-  }
-  cleanup();
-  if (rc) return rc;
-  for (size_t i = 0; i < h_ids.size(); i++) out_ids[i] = h_ids[i] == PH_EMPTY32 ? PHNSW_EMPTY : h_ids[i];
-  memcpy(out_d, h_d.data(), h_d.size() * 4);
-  for (uint64_t i = 0; i < nq; i++) out_len[i] = h_len[i];
-  if (out_stats)
-    for (uint64_t i = 0; i < 2 * nq; i++) out_stats[i] = h_st[i];
-  return 0;
+  return ph_search_host(ix, queries, qids, nq, sp, upto, exclude, 0, out_ids, out_d, out_len, out_stats, knn_mode, nullptr);
 }
-
-extern "C" int phnsw_search_batch(const phnsw_index *ix, const float *queries, uint64_t nq,
-                                  const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
-                                  uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
-  if (!queries && nq) {
-    ph_set_error("phnsw_search_batch: queries is NULL");
-    return PHNSW_E_INVALID;
-  }
-  return search_host(ix, queries, nullptr, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
-} catch (...) { return ph_caught(); }
-
-extern "C" int phnsw_search_batch_stored(const phnsw_index *ix, const uint64_t *qids, uint64_t nq,
-                                         const phnsw_search_params *sp, uint32_t upto_layers, const uint64_t *exclude,
-                                         uint64_t *out_ids, float *out_d, uint64_t *out_len, uint64_t *out_stats) try {
-  if (!qids && nq) {
-    ph_set_error("phnsw_search_batch_stored: qids is NULL");
-    return PHNSW_E_INVALID;
-  }
-  return search_host(ix, nullptr, qids, nq, sp, upto_layers, exclude, out_ids, out_d, out_len, out_stats, 0);
-} catch (...) { return ph_caught(); }
 
 // Hnsw::knn  src/lib.rs:905-928: queue of 3k seeded with (self, 0.0), closest_nodes on the
 // bottom layer, drop self, take k

@@ -124,6 +124,8 @@ struct PhWorkspace {
   size_t tiny_pq_bytes = 0, tiny_pn_bytes = 0;
   uint2 *dense_ovf = nullptr;  // spill lists of the dense-only launch: [its resident waves][table nodes]
   size_t dense_ovf_bytes = 0;
+  uint32_t *ovf_s = nullptr;  // search_instrumented: index sums of the spilled entries, [n_slots][ovf_cap]
+  size_t ovf_s_cap = 0;
   // per-dispatch bookkeeping of the last descent (phnsw_last_search_dispatches): evd[0] closes the
   // dense-top-layer kernels, evd[1 + i] search launch i; dtotals[i] = {distance evaluations, hops}
   hipEvent_t evd[PH_MAX_DISPATCH + 1] = {};
@@ -134,7 +136,10 @@ struct PhWorkspace {
 };
 
 struct PhPendingLayer;
+struct PhHostStage;  // hostpath.hip: persistent staging of the host-pointer search entry points
 struct phnsw_index {
+  std::vector<PhHostStage *> stages;  // handed out under stage_mutex, one per concurrent host-pointer call
+  std::mutex stage_mutex;
   PhPendingLayer *pending = nullptr;  // layer under construction (phase API, build.hip)
   phnsw_store *store = nullptr;
   std::vector<PhLayerHost> layers;  // top first (src/lib.rs:587)
@@ -203,6 +208,8 @@ struct PhSearchArgs {
   const uint32_t *order;  // nullable: processing order (a permutation of 0..nq-1), see search.hip
   uint32_t seg;           // order != nullptr: positions per XCD segment
   uint32_t *out_hit;    // nullable: 1 when a Stored query found itself (stochastic_recall lib.rs:1492)
+  uint32_t *out_index;  // nullable: Hnsw::search_instrumented's index_distance per query (selects the INSTR kernels)
+  uint32_t *ovf_s;      // ... and the index sums of the spilled entries, parallel to ovf
   // dense top layers (tiny.hip): layers [0, tiny_layers) of this launch hold <= PH_TINY_MAX_NODES
   // nodes; the distance of every query to every node of layer tiny_layers - 1 sits in tiny_d
   // (same bits as the per-hop evaluation), the traversal of those layers runs in the id space
@@ -223,6 +230,7 @@ void ph_pool_free(void *p);
 void ph_pool_trim(void);  // give everything cached back to the driver
 void ph_layer_free(PhLayerHost &l);
 void ph_pending_free(phnsw_index *ix);
+void ph_host_stages_free(phnsw_index *ix);  // hostpath.hip
 int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
                     PhLayerHost *out);
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
@@ -230,7 +238,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride = 0,
                      uint32_t *out_hit = nullptr, float threshold = 0.f, uint32_t first_node = 0,
-                     float hit_eps = 0.f, const uint32_t *order = nullptr);
+                     float hit_eps = 0.f, const uint32_t *order = nullptr, uint32_t *out_index = nullptr);
 // locality schedule helpers (group.hip / api.hip)
 #define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
 #define PH_POS_MIN 256u     // smaller layers carry no cells (their node id is the key)

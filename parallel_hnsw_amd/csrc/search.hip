@@ -55,7 +55,12 @@
 #define PH_TICK(k)
 #endif
 
-template <int CAPC, class Dist>
+// INSTR: Hnsw::search_instrumented (lib.rs:667-673).  Every visit_queue entry of the reference carries the
+// index_sum of its discovery path (lib.rs:211-220: parent's sum + 1-based rank in the parent's sorted batch); the
+// value returned is the index_sum of the node expanded at the last hop of the bottom layer that changed
+// candidates.first() (lib.rs:225-231).  The sums ride along in a third queue array (the prefix scratch S, idle
+// during the hops) and a parallel spill array; the plain kernels compile none of it.
+template <int CAPC, class Dist, bool INSTR = false>
 __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   extern __shared__ uint32_t smem[];
   constexpr int CAP = CAPC * 64;
@@ -84,6 +89,8 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   uint32_t *vis = a.visited + (uint64_t)blockIdx.x * a.visited_words;
   uint2 *ovf = DENSE_ONLY ? a.dense_ovf + (uint64_t)blockIdx.x * a.dense_ovf_cap : a.ovf + (uint64_t)blockIdx.x * a.ovf_cap;
   const uint32_t ovf_cap = DENSE_ONLY ? a.dense_ovf_cap : a.ovf_cap;
+  uint32_t *const Qs = S;
+  uint32_t *const ovf_s = INSTR ? a.ovf_s + (uint64_t)blockIdx.x * a.ovf_cap : nullptr;
 
   // locality schedule: with an `order` the query list is cut into 8 consecutive segments, one
   // per XCD, so that the queries one L2 serves together are neighbours in `order`; a wave
@@ -138,6 +145,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       dist.prepare_stored(a.dist, qvec, dist_lds, lane);
     const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
     uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
+    uint32_t index_distance = 0xFFFFFFFFu;  // usize::MAX until a layer has run  search.rs:112
     uint32_t n_dist0 = 0, n_hops0 = 0;  // counters a split descent brought in from its earlier launches
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
@@ -268,6 +276,13 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       // ---- closest_nodes  lib.rs:175-248
       uint32_t ovf_n = 0;
       uint32_t pd = a.probe_depth;
+      uint32_t highest = 0;  // highest_improvement  lib.rs:190
+      if constexpr (INSTR) {
+#pragma unroll
+        for (int c = 0; c < CAPC; c++)
+          if (lane + 64u * c < qlen) Qs[lane + 64u * c] = 0u;  // seeds: NodeDistance::ZERO  lib.rs:182-185
+        __syncthreads();
+      }
       // every queue entry below scan_from has been expanded: the pop scan starts at its 64-entry chunk,
       // and a hop's merge touches only the chunks from its first insertion point on
       uint32_t scan_from = 0;
@@ -327,7 +342,10 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           cur = (uint32_t)best & IDM;
           if (lane == 0)
             __hip_atomic_store(&ovf[bi].x, cur | EXPF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pop = -1 - (int)bi;  // INSTR reads the spilled entry's index_sum below
         }
+        uint32_t cur_s = 0;
+        if constexpr (INSTR) cur_s = pop >= 0 ? Qs[pop] : ovf_s[(uint32_t)(-1 - pop)];
         cur &= IDM;
         n_hops++;
         PH_TICK(0)
@@ -385,6 +403,17 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         // as one parallel rank-merge.  Batch keys are distinct and absent from the queue
         // (visited), so final slot = (#queue keys below) + (#batch keys below).
         const uint64_t key = fresh ? mkkey(myd, nb) : KEY_NONE;
+        uint32_t my_s = 0;
+        if constexpr (INSTR) {  // (ix, (n, d)) of the sorted batch: index_sum + ix + 1  lib.rs:211-220
+          uint32_t rank_all = 0;
+          uint64_t remf = fm;
+          while (remf) {
+            const int j = __builtin_ctzll(remf);
+            remf &= remf - 1;
+            rank_all += (rl64(key, j) < key) ? 1u : 0u;
+          }
+          my_s = cur_s + rank_all + 1u;
+        }
         // An element that is worse than the tail of a FULL queue cannot enter it: it goes straight to
         // the spill list and takes no part in the merge.  Late in a layer most hops bring nothing
         // else; those skip the merge altogether.
@@ -430,6 +459,11 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               qd0 = Qd[i0];
             }
             const uint64_t qk0 = two ? mkkey(qd0, qi0) : KEY_NONE;
+            uint32_t qs1 = 0, qs0 = 0;
+            if constexpr (INSTR) {
+              qs1 = has1 ? Qs[i1] : 0u;
+              qs0 = two ? Qs[i0] : 0u;
+            }
             uint32_t sh1 = 0, sh0 = 0;
             uint64_t rem = im;
             if (first_pass) {
@@ -462,10 +496,12 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
             if (has1 && np1 < ef) {
               Qid[np1] = qi1;
               Qd[np1] = qd1;
+              if constexpr (INSTR) Qs[np1] = qs1;
             }
             if (two && np0 < ef) {
               Qid[np0] = qi0;
               Qd[np0] = qd0;
+              if constexpr (INSTR) Qs[np0] = qs0;
             }
             if (qlen + 64u > ef) {  // only a queue within 64 entries of its capacity can push anything out
               const bool spill1 = has1 && np1 >= ef;
@@ -473,6 +509,8 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               if (sm1) {
                 const uint32_t at = ovf_n + __popcll(sm1 & lt);
                 if (spill1 && at < ovf_cap) ovf[at] = make_uint2(qi1, __float_as_uint(qd1));
+                if constexpr (INSTR)
+                  if (spill1 && at < ovf_cap) ovf_s[at] = qs1;
                 ovf_n += __popcll(sm1);
               }
               const bool spill0 = two && np0 >= ef;
@@ -480,6 +518,8 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               if (sm0) {
                 const uint32_t at = ovf_n + __popcll(sm0 & lt);
                 if (spill0 && at < ovf_cap) ovf[at] = make_uint2(qi0, __float_as_uint(qd0));
+                if constexpr (INSTR)
+                  if (spill0 && at < ovf_cap) ovf_s[at] = qs0;
                 ovf_n += __popcll(sm0);
               }
             }
@@ -500,14 +540,19 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           if (fresh && newpos < ef) {
             Qid[newpos] = nb;
             Qd[newpos] = myd;
+            if constexpr (INSTR) Qs[newpos] = my_s;
           }
           bool spill = fresh && newpos >= ef;
           uint64_t sm = __ballot(spill);
           if (sm) {
             uint32_t at = ovf_n + __popcll(sm & lt);
             if (spill && at < ovf_cap) ovf[at] = make_uint2(nb, __float_as_uint(myd));
+            if constexpr (INSTR)
+              if (spill && at < ovf_cap) ovf_s[at] = my_s;
             ovf_n += __popcll(sm);
           }
+          if constexpr (INSTR)  // current_best != candidates.first(): a new entry took slot 0  lib.rs:225-231
+            if (__ballot(fresh && newpos == 0u)) highest = cur_s;
         }
         qlen = min(ef, qlen + m);
         scan_from = min(pop >= 0 ? (uint32_t)pop + 1u : scan_from, pos_min);
@@ -523,6 +568,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
       }
       if (err != ST_OK) break;
+      if constexpr (INSTR) index_distance = highest;  // last_index_distance = index_distance  search.rs:135
 #ifdef PH_CELL_PROBE
       if (probing && lane == 0) {
         for (int k = 0; k < 11; k++) atomicAdd(&a.probe_out[k], (unsigned long long)probe_cnt[k]);
@@ -707,6 +753,8 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       atomicAdd(&a.launch_totals[0], (unsigned long long)(n_dist - n_dist0));
       atomicAdd(&a.launch_totals[1], (unsigned long long)(n_hops - n_hops0));
     }
+    if constexpr (INSTR)
+      if (lane == 0) a.out_index[q] = index_distance;
     if (lane == 0) {
       a.out_len[q] = clen;
       a.status[q] = err;
@@ -738,6 +786,12 @@ __global__ __launch_bounds__(64) void ph_search_kernel_dense(PhSearchArgs a) {
 template <int CAPC, int NV>
 __global__ __launch_bounds__(64, 1) void ph_search_kernel_lat(PhSearchArgs a) {
   ph_search_body<CAPC, DistF32<NV, 0>>(a);
+}
+
+// Hnsw::search_instrumented: the same body carrying index sums (f32 stores; queues of 512 or 1024 slots)
+template <int CAPC, int NV>
+__global__ __launch_bounds__(64) void ph_search_kernel_instr(PhSearchArgs a) {
+  ph_search_body<CAPC, DistF32<NV>, true>(a);
 }
 
 // the register-table policy keeps a whole lookup table in VGPRs: two waves per SIMD is its register budget
@@ -789,6 +843,14 @@ static ph_search_fn pick_kernel_dense(int capc) {
   return nullptr;
 }
 
+static ph_search_fn pick_kernel_instr(int capc, int nv) {
+#define PH_KI(C, N) \
+  if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel_instr<C, N>;
+  PH_KI(8, 1) PH_KI(8, 3) PH_KI(8, 6) PH_KI(16, 1) PH_KI(16, 3) PH_KI(16, 6)
+#undef PH_KI
+  return nullptr;
+}
+
 #define PH_LATENCY_MAX 1024u  // batches up to this many queries run the latency kernels (PHNSW_NO_LAT=1: never)
 static ph_search_fn pick_kernel_lat(int capc, int nv) {
 #define PH_KL(C, N) \
@@ -822,6 +884,10 @@ uint32_t ph_search_slots(uint32_t ef, uint32_t nv4, bool pq, size_t pq_lds, int 
   if (!capc || (!pq && !nv)) return 0;
   ph_search_fn fn = pqr_m == -1 ? pick_kernel_pqs(capc, nv) : (pqr_m ? pick_kernel_pqr(capc, pqr_m) : pick_kernel(capc, nv));
   if (pqr_m == -2) fn = pick_kernel_lat(capc, nv);
+  if (pqr_m == -3) {
+    capc = std::max(capc, 8);
+    fn = pick_kernel_instr(capc, nv);
+  }
   if (!fn) return 0;
   int dev = 0;
   hipGetDevice(&dev);
@@ -855,6 +921,7 @@ void ph_workspace_free(PhWorkspace &ws) {
     if (e) hipEventDestroy(e);
   if (ws.dtotals) hipFree(ws.dtotals);
   if (ws.dense_ovf) hipFree(ws.dense_ovf);
+  if (ws.ovf_s) hipFree(ws.ovf_s);
   ph_workspace_order_free(ws);
   ph_tiny_free(ws);
   ws = PhWorkspace();
@@ -986,6 +1053,23 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   if (!pq && !pqr && a.nq <= PH_LATENCY_MAX && !getenv("PHNSW_NO_LAT") && pick_kernel_lat(capc, nv)) {
     fn = pick_kernel_lat(capc, nv);
     lat = -2;
+  }
+  if (a.out_index) {  // Hnsw::search_instrumented
+    if (pq || pqr) {
+      ph_set_error("search_instrumented: f32 stores only");
+      return PHNSW_E_UNSUPPORTED;
+    }
+    capc = std::max(capc, 8);
+    fn = pick_kernel_instr(capc, nv);
+    lat = -3;
+    if (ws.ovf_s_cap < (size_t)ws.n_slots * ws.ovf_cap) {
+      if (ws.ovf_s) PH_HIP(hipFree(ws.ovf_s));
+      ws.ovf_s = nullptr;
+      ws.ovf_s_cap = 0;
+      PH_HIP(hipMalloc(&ws.ovf_s, (size_t)ws.n_slots * ws.ovf_cap * 4));
+      ws.ovf_s_cap = (size_t)ws.n_slots * ws.ovf_cap;
+    }
+    a.ovf_s = ws.ovf_s;
   }
   if (!fn) {
     ph_set_error("unsupported search shape: ef=%u nv4=%u", a.ef, a.dist.nv4);

@@ -501,10 +501,41 @@ class Hnsw:
         return n.value
 
     # -- search -------------------------------------------------------------
-    def search_batch(self, queries=None, qids=None, sp=None, exclude=None, upto=0, stats=False):
-        """Hnsw::search for many queries; returns (ids[nq, ef] u64, d[nq, ef] f32, len[nq])"""
+    def search_batch(self, queries=None, qids=None, sp=None, exclude=None, upto=0, stats=False, k=None):
+        """Hnsw::search for many queries; returns (ids[nq, ef] u64, d[nq, ef] f32, len[nq]); with k only the best k
+        results of each query are transferred (phnsw_search_batch_topk): ids[nq, k], d[nq, k]"""
         sp = sp or SearchParameters()
         ef = sp.number_of_candidates
+        q = qi = None
+        if queries is not None:
+            q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+            assert q.shape[1] == self.store.dim
+            nq = q.shape[0]
+        else:
+            qi = np.ascontiguousarray(qids, dtype=np.uint64)
+            nq = len(qi)
+        w = ef if k is None else int(k)
+        ids = np.empty((nq, w), dtype=np.uint64)
+        d = np.empty((nq, w), dtype=np.float32)
+        ln = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros((nq, 2), dtype=np.uint64) if stats else None
+        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint64)
+        if k is not None:
+            assert not stats
+            check(lib().phnsw_search_batch_topk(self._h, _p(q), _p(qi), nq, C.byref(sp), upto, _p(ex), w, _p(ids), _p(d),
+                                                _p(ln)))
+        elif queries is not None:
+            check(lib().phnsw_search_batch(self._h, _p(q), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d), _p(ln), _p(st)))
+        else:
+            check(lib().phnsw_search_batch_stored(self._h, _p(qi), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d),
+                                                  _p(ln), _p(st)))
+        return (ids, d, ln, st) if stats else (ids, d, ln)
+
+    def search_instrumented_batch(self, queries=None, qids=None, sp=None):
+        """Hnsw::search_instrumented (lib.rs:667-673) for many queries -> ids, d, len, index_distance[nq] u64"""
+        sp = sp or SearchParameters()
+        ef = sp.number_of_candidates
+        q = qi = None
         if queries is not None:
             q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
             assert q.shape[1] == self.store.dim
@@ -515,14 +546,17 @@ class Hnsw:
         ids = np.empty((nq, ef), dtype=np.uint64)
         d = np.empty((nq, ef), dtype=np.float32)
         ln = np.zeros(nq, dtype=np.uint64)
-        st = np.zeros((nq, 2), dtype=np.uint64) if stats else None
-        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint64)
-        if queries is not None:
-            check(lib().phnsw_search_batch(self._h, _p(q), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d), _p(ln), _p(st)))
+        idx = np.zeros(nq, dtype=np.uint64)
+        check(lib().phnsw_search_instrumented(self._h, _p(q), _p(qi), nq, C.byref(sp), _p(ids), _p(d), _p(ln), _p(idx)))
+        return ids, d, ln, idx
+
+    def search_instrumented(self, v, sp=None):
+        """Hnsw::search_instrumented(v, sp) -> (Vec<(VectorId, f32)>, usize)  lib.rs:667-673"""
+        if isinstance(v, Stored):
+            ids, d, ln, idx = self.search_instrumented_batch(qids=[v.id], sp=sp)
         else:
-            check(lib().phnsw_search_batch_stored(self._h, _p(qi), nq, C.byref(sp), upto, _p(ex), _p(ids), _p(d),
-                                                  _p(ln), _p(st)))
-        return (ids, d, ln, st) if stats else (ids, d, ln)
+            ids, d, ln, idx = self.search_instrumented_batch(queries=v.vec if isinstance(v, Unstored) else v, sp=sp)
+        return [(int(ids[0, i]), d[0, i]) for i in range(int(ln[0]))], int(idx[0])
 
     def search_batch_device(self, nq, sp, out_ids, out_d, out_len, status, queries=0, ldq=0, qids=0, exclude=0,
                             out_stats=0, upto=0, stream=0):

@@ -304,3 +304,113 @@ def test_hnsw_accessors_mirror_the_crate():
     assert list(g.all_vectors()) == list(range(800))
     np.testing.assert_array_equal(g.supers_for_layer(0), g.get_layer(1).nodes)
     assert list(g.supers_for_layer(L - 1)) == [g.entry_vector()]
+
+
+@pytest.mark.parametrize("n,dim,ef,pd,metric", [(3000, 64, 64, 2, 0), (20000, 96, 300, 3, 1), (6000, 768, 600, 2, 0),
+                                                 (4000, 32, 40, 4, 2)])
+def test_search_instrumented_equals_the_oracle(n, dim, ef, pd, metric):
+    """Hnsw::search_instrumented (lib.rs:667-673): results AND the index_distance of search_layers_instrumented
+    (search.rs:93-140 / lib.rs:211-231: index sums carried by every visit_queue entry) against the oracle, for raw and
+    stored queries; the results equal the plain search's"""
+    rows = oracle.synth_rows(0, n, dim, normalize=metric != 2)
+    oix = oracle.Index.generate(rows, np.arange(n), oracle.default_build_params(seed=3), dim=dim, metric=metric,
+                                sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim], metric=metric)
+    gix = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)])
+    q = oracle.synth_rows(2 ** 32, 200, dim, normalize=metric != 2)[:, :dim]
+    sp, spo = ph.SearchParameters(ef, ef, pd), (ef, ef, pd)
+    gi, gd, gl, gx = gix.search_instrumented_batch(queries=q, sp=sp)
+    ci, cd, cl, cx = oix.search_instrumented(queries=q, sp=spo)
+    np.testing.assert_array_equal(gi, ci)
+    np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32))
+    np.testing.assert_array_equal(gl, cl)
+    np.testing.assert_array_equal(gx, cx)
+    assert (gx > 0).any()
+    first_raw = int(cx[0])
+    pi, pdist, pl = gix.search_batch(queries=q, sp=sp)
+    np.testing.assert_array_equal(gi, pi)
+    qid = np.arange(0, n, 37, dtype=np.uint64)
+    gi, gd, gl, gx = gix.search_instrumented_batch(qids=qid, sp=sp)
+    ci, cd, cl, cx = oix.search_instrumented(qids=qid, sp=spo)
+    np.testing.assert_array_equal(gi, ci)
+    np.testing.assert_array_equal(gx, cx)
+    res, idx = gix.search_instrumented(ph.Unstored(q[0]), sp)
+    assert idx == first_raw and len(res) == int(pl[0]) and res[0][0] == int(pi[0, 0])
+
+
+def test_search_instrumented_spill_path(monkeypatch):
+    """the index sums of entries that fall out of the queue travel through the spill list (small queue, deep probe,
+    a 64-entry list forces the overflow -> re-run path as well)"""
+    n, dim = 8000, 32
+    rows = oracle.synth_rows(0, n, dim)
+    oix = oracle.Index.generate(rows, np.arange(n), oracle.default_build_params(seed=5), dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim])
+    q = oracle.synth_rows(2 ** 32, 64, dim)[:, :dim]
+    for cap in (None, "64"):
+        if cap:
+            monkeypatch.setenv("PHNSW_OVF_CAP", cap)
+        gix = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)])
+        gi, gd, gl, gx = gix.search_instrumented_batch(queries=q, sp=ph.SearchParameters(8, 8, 40))
+        ci, cd, cl, cx = oix.search_instrumented(queries=q, sp=(8, 8, 40))
+        np.testing.assert_array_equal(gi, ci)
+        np.testing.assert_array_equal(gx, cx)
+
+
+def test_host_path_topk_and_pipelined_chunks(monkeypatch):
+    """the host-pointer entry points (csrc/hostpath.hip): top-k transfer == the leading columns of the whole queue;
+    a list cut into many pipelined chunks (two staging slots, two streams) == the same list in one piece, for raw
+    and stored queries with exclude and counters; repeated calls reuse the staging"""
+    n, dim = 20000, 96
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    h = ph.Hnsw.generate(store, np.arange(n), ph.BuildParameters(seed=2))
+    q = ph.VectorStore.synthetic(1500, dim, seed=42, first=2 ** 32).read()
+    sp = ph.SearchParameters(100, 100, 3)
+    full = h.search_batch(queries=q, sp=sp, stats=True)
+    for k in (1, 10, 100):
+        ti, td, tl = h.search_batch(queries=q, sp=sp, k=k)
+        np.testing.assert_array_equal(ti, full[0][:, :k])
+        np.testing.assert_array_equal(td.view(np.uint32), full[1][:, :k].view(np.uint32))
+        np.testing.assert_array_equal(tl, np.minimum(full[2], k))
+    qid = np.arange(0, n, 13, dtype=np.uint64)
+    sfull = h.search_batch(qids=qid, sp=sp, exclude=qid, stats=True)
+    monkeypatch.setenv("PHNSW_HOST_CHUNKS", "64,16,100")   # pipeline from 64 queries on: first chunk 16, pieces of <= 100
+    for _ in range(2):
+        got = h.search_batch(queries=q, sp=sp, stats=True)
+        for a, b in zip(got, full):
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                          b.view(np.uint32) if b.dtype == np.float32 else b)
+        got = h.search_batch(qids=qid, sp=sp, exclude=qid, stats=True)
+        for a, b in zip(got, sfull):
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                          b.view(np.uint32) if b.dtype == np.float32 else b)
+        ti, td, tl = h.search_batch(queries=q, sp=sp, k=7)
+        np.testing.assert_array_equal(ti, full[0][:, :7])
+    assert not (sfull[0] == qid[:, None]).any()
+
+
+def test_host_path_concurrent_callers():
+    """search entry points are thread safe (Hnsw::search takes &self and is called from the Rayon pool,
+    lib.rs:1107-1117): four threads share one index, each call gets a staging set of its own"""
+    import threading
+    n, dim = 20000, 64
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    h = ph.Hnsw.generate(store, np.arange(n), ph.BuildParameters(seed=2))
+    sp = ph.SearchParameters(64, 64, 2)
+    qs = [ph.VectorStore.synthetic(300 + 50 * t, dim, seed=42, first=2 ** 32 + 1000 * t).read() for t in range(4)]
+    want = [h.search_batch(queries=x, sp=sp) for x in qs]
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            for _ in range(5):
+                got[t] = h.search_batch(queries=qs[t], sp=sp)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for t in range(4):
+        np.testing.assert_array_equal(got[t][0], want[t][0])
+        np.testing.assert_array_equal(got[t][1].view(np.uint32), want[t][1].view(np.uint32))
