@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     help="N > 1: do not measure the sharded index build after the search measurement")
     ap.add_argument("--sharded-timeout", type=int, default=300, help="N > 1: watchdog of the sharded build, seconds")
     ap.add_argument("--keep-pmc", default="", help="driver: copy the counter CSVs of the passes into this directory")
-    ap.add_argument("--role", default="", choices=["", "driver", "worker", "pmc"])
+    ap.add_argument("--role", default="", choices=["", "driver", "worker", "pmc", "pmc_build"])
     ap.add_argument("--dump-index", default="", help="worker: serialise the headline index + parameters here")
     ap.add_argument("--index-dir", default="", help="pmc: directory written by --dump-index")
     return ap.parse_args(argv)
@@ -396,12 +396,18 @@ def worker(args):
                               "note": "distance table of every query x every node of the largest dense layer; f32, the per-hop "
                                       "path's bits; ms includes the table-id rewrite and operand packing kernels"})
             else:
+                gathered = x["n_dist"] - x["n_table"]
                 e.update({"kernel": "ph_search_kernel", "layers": "%d-%d" % (lo, hi - 1), "distance_evals": x["n_dist"],
-                          "hops": x["n_hops"],
-                          "alg_GB": round(alg_bytes_of(x["n_dist"], x["n_hops"], widths[hi - 1], row_bytes,
-                                                       args.nq * ef if i == len(disp) - 1 else 0) / 1e9, 3)})
+                          "table_lookups": x["n_table"], "gathered_rows": gathered, "hops": x["n_hops"],
+                          "gathered_GB": round(alg_bytes_of(gathered, x["n_hops"], widths[hi - 1], row_bytes,
+                                                            args.nq * ef if i == len(disp) - 1 else 0) / 1e9, 3)})
             dispatches.append(e)
         alg_bytes = alg_bytes_of(n_dist, n_hops, widths[-1], row_bytes, args.nq * ef)
+        n_table = sum(x["n_table"] for x in disp)
+        # what the search kernel has to move: the rows of the evaluations no table serves + neighbour rows + results
+        gathered_bytes = alg_bytes_of(n_dist - n_table, n_hops, widths[-1], row_bytes, args.nq * ef)
+        search_ms = float(sum(np.mean(x["ms"]) for x in disp[1:]))
+        table_ms = float(np.mean(disp[0]["ms"]))
         # ---- latency side (batch sizes 1, 64, 1 024, 10 000), isolated launches
         batch_sweep = []
         if rank == 0:
@@ -421,7 +427,7 @@ def worker(args):
             big = {"queries": 100_000, "kernel_ms": round(ms, 3), "queries_per_s": round(100_000 / ms * 1e3),
                    "recall_at_10": round(recall_at_10(rb.result_ids(ef), gtb), 4),
                    "dispatches": [{"layers": "%d-%d" % (x["layers"][0], x["layers"][1] - 1) if i else "dense top layers",
-                                   "ms": round(x["ms"], 3), "distance_evals": x["n_dist"]}
+                                   "ms": round(x["ms"], 3), "distance_evals": x["n_dist"], "table_lookups": x["n_table"]}
                                   for i, x in enumerate(index.dispatches())]}
             log("100 000-query batch: %.2f ms = %.0f q/s" % (ms, 100_000 / ms * 1e3))
             del rb, qbig, gtb
@@ -431,15 +437,18 @@ def worker(args):
                        "dispatches_per_launch": len(disp)}, open(os.path.join(args.dump_index, "bench_meta.json"), "w"))
         build_bytes = binfo["build_distance_evals"] * row_bytes + binfo["build_hops"] * widths[-1] * 4
         res = dict(binfo, dataset=kind, ef=ef, upper=up, probe_depth=pd, recall_target_met=met, recall_at_10=round(rec, 4),
-                   elapsed=elapsed, kernel_ms=float(np.mean(kms)), alg_bytes=alg_bytes, n_dist_per_query=n_dist / args.nq,
+                   elapsed=elapsed, kernel_ms=float(np.mean(kms)), alg_bytes=alg_bytes, gathered_bytes=gathered_bytes,
+                   n_table=n_table, search_ms=search_ms, table_ms=table_ms, n_dist_per_query=n_dist / args.nq,
                    n_hops_per_query=n_hops / args.nq, sweep=sweep, batch_sweep=batch_sweep, dispatches=dispatches,
                    batch_100k=big,
                    build_roofline={"bound": "hbm", "distance_evals": binfo["build_distance_evals"], "hops": binfo["build_hops"],
-                                   "algorithmic_bytes": build_bytes, "algorithmic_gbs": round(build_bytes / binfo["build_s"] / 1e9, 1),
+                                   "evals_equivalent_bytes": build_bytes,
+                                   "evals_equivalent_gbs": round(build_bytes / binfo["build_s"] / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "note": "algorithmic row bytes of the build's searches (K2 = 92 % of the build's GPU time) over "
-                                           "the whole build wall time; upper layers are served from the dense tables and from "
-                                           "cache, so this is not an HBM fraction; per rank when sharded"})
+                                   "note": "SURVEY 8d's literal figure: EVERY evaluation of the build's searches x row bytes over the "
+                                           "build's wall time -- a work rate, not a memory rate (most upper-layer evaluations are "
+                                           "table look-ups); the driver adds `kernels`: bytes and milliseconds per kernel family "
+                                           "from a rocprofv3 --pmc --kernel-trace pass over a build of the same index"})
         return res, store, index, qstore, run, sp, gt
 
     def secondary(kind, cells, batch_cells=(), latency_cell=None):
@@ -484,6 +493,14 @@ def worker(args):
     pq = None
     if rank == 0 and world == 1 and not args.no_pq and not args.ef:
         pq = pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, stream)
+
+    host_path = None
+    if rank == 0 and world == 1:
+        host_path = host_path_cells(args, log, ph, torch, index, qstore, run, sp)
+
+    sharded_model = None
+    if rank == 0 and world == 1 and not args.no_sharded_build and not args.ef:
+        sharded_model = sharded_build_model(args, log, ph, store, index, res["build_s"])
 
     extras = {}
     if rank == 0 and world == 1 and not args.ef:
@@ -536,17 +553,40 @@ def worker(args):
             # `achieved` is filled by the driver from the rocprofv3 --pmc passes of this run (memory-side bytes of
             # one launch / kernel_ms); without them it stays null: algorithmic bytes over time can exceed the HBM
             # peak (rows shared through L2 / the dense tables), which is not a roofline fraction
-            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                         "traffic_source": None,
-                         "kernel": "ph_search_kernel (+ ph_tiny_table_mfma_kernel)", "kernel_ms": round(res["kernel_ms"], 4),
-                         "kernel_ms_note": "HIP events on the launch stream around one isolated launch (all its dispatches), "
-                                           "mean of %d launches after the timed region" % min(args.steps, 10),
-                         "algorithmic_bytes_per_launch": res["alg_bytes"],
-                         "algorithmic_gbs": round(res["alg_bytes"] / ktime / 1e9, 1),
+            # Contract form, <= 1 by construction: `achieved` = ALGORITHMIC bytes of the dominant kernel (ph_search_kernel:
+            # the rows of the evaluations no dense table serves x row bytes + neighbour rows + results, counted by the
+            # kernel = the oracle's counts) / that kernel's own milliseconds (HIP events on the launch stream);
+            # `traffic` = the memory-side bytes of the same kernel from this run's rocprofv3 --pmc passes (filled by the
+            # driver); the table kernel has its own MFMA roofline under `mfma`.
+            "roofline": {"bound": "hbm", "achieved": round(res["gathered_bytes"] / (res["search_ms"] * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(res["gathered_bytes"] / (res["search_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "traffic_source": None, "traffic_ratio": None,
+                         "kernel": "ph_search_kernel<8, DistF32<3, 4>>", "kernel_ms": round(res["search_ms"], 4),
+                         "launch_ms": round(res["kernel_ms"], 4),
+                         "kernel_ms_note": "HIP events on the launch stream, mean of %d isolated launches after the timed region; "
+                                           "kernel_ms = the search kernel alone, launch_ms = all dispatches of one launch (table "
+                                           "kernels + search kernel).  An isolated launch exposes its enqueue gaps and its "
+                                           "own tail; back-to-back steps hide them under the next step's head, so launch_ms "
+                                           "may exceed ms_per_step by a fraction of a percent" % min(args.steps, 10),
+                         "algorithmic_bytes_per_launch": res["gathered_bytes"],
+                         "gathered_rows_per_launch": int(round(res["n_dist_per_query"] * args.nq)) - res["n_table"],
+                         "table_lookups_per_launch": res["n_table"],
+                         "algorithmic_definition": "gathered rows x %d B + hops x W x 4 B + results x 12 B (SURVEY 8d with the "
+                                                   "evaluations the dense tables serve taken out: those move no row)" % ((args.dim + 3) // 4 * 16),
+                         "evals_equivalent_gbs": round(res["alg_bytes"] / ktime / 1e9, 1),
+                         "evals_equivalent_note": "SURVEY 8d's literal figure (EVERY evaluation x row bytes) over the whole launch: "
+                                                  "a work rate, not a memory rate -- it exceeds the HBM peak because %d %% of the "
+                                                  "evaluations are table look-ups" % round(100.0 * res["n_table"] / max(1.0, res["n_dist_per_query"] * args.nq)),
+                         "mfma": next(({"kernel": "ph_tiny_table_mfma_kernel (+ prep + 2 x pack)", "bound": "mfma", "flop": x["flop"],
+                                        "ms": x["ms"], "achieved": x["tflops"], "peak": x["peak_tflops"], "unit": "TFLOP/s",
+                                        "frac": x["frac"]} for x in res["dispatches"][:1] if "flop" in x), None),
                          "dispatches": res["dispatches"], "source_hash": source_hash()},
             "ground_truth": dict(gt_info, note="exact top-10 by brute force on the f32 MFMA units; mfma bound"),
             "cpu_baseline": cpu,
             "pq": pq,
+            "host_path": host_path,
+            "sharded_build_model": sharded_model,
             "batch_sweep": res["batch_sweep"],
             "batch_100k": res["batch_100k"],
             "build_roofline": res["build_roofline"],
@@ -583,6 +623,75 @@ def worker(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_path_cells(args, log, ph, torch, index, qstore, run, sp):
+    """the drop-in boundary itself: queries in HOST memory in, u64 ids in host memory out (phnsw_search_batch_topk,
+    what Hnsw::search binds to), beside the device-resident launch of the same batch.  Never `value`."""
+    import numpy as np
+    try:
+        q_all = qstore.read()
+        out = []
+        for nq in (1, 64, 1024, 10000):
+            if nq > qstore.n:
+                break
+            q = np.ascontiguousarray(q_all[:nq])
+            dev_ms = run.isolated_ms(sp, nq, reps=3)
+            cell = {"queries": nq, "device_resident_kernel_ms": round(dev_ms, 3)}
+            for label, k in (("top10", 10), ("whole_queue", None)):
+                best = 1e9
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    index.search_batch(queries=q, sp=sp, k=k)
+                    best = min(best, time.perf_counter() - t0)
+                cell[label + "_ms"] = round(best * 1e3, 3)
+                cell[label + "_queries_per_s"] = round(nq / best)
+                cell[label + "_over_device_resident"] = round(best * 1e3 / dev_ms, 3)
+            out.append(cell)
+            log("host path %5d queries: device-resident %.3f ms, host top-10 %.3f ms, whole queue %.3f ms" % (
+                nq, dev_ms, cell["top10_ms"], cell["whole_queue_ms"]))
+        return {"entry_points": "phnsw_search_batch_topk (k = 10) / phnsw_search_batch (k = number_of_candidates): pageable "
+                                "host queries in, u64 ids + f32 distances out, wall time of the call from Python",
+                "how": "persistent per-index staging, chunks pipelined over two streams, top-k narrowed and widened to u64 on "
+                       "the device (csrc/hostpath.hip)", "cells": out}
+    except Exception as exc:
+        log("host path measurement failed: %r" % (exc,))
+        return {"error": repr(exc)}
+
+
+def sharded_build_model(args, log, ph, store, index, single_s):
+    """BASELINE config 4's driver on this one GPU: phnsw_build_sharded with an emulated world of 8 -- every rank's share
+    of every phase runs here in turn through the driver's real split / block layout / reassembly -- gives rank 0's
+    critical path (measured) + the all-gather (modelled at ONE xGMI link, 50 GB/s; RCCL's mesh is faster)"""
+    import numpy as np
+    from parallel_hnsw_amd.sharded import EmulatedComm, build_sharded
+    try:
+        w = 8
+        h, st = build_sharded(store, np.arange(store.n, dtype=np.uint64), ph.BuildParameters(), EmulatedComm(w, 0))
+        same = h.layer_count() == index.layer_count() and all(
+            np.array_equal(h._layer(l).neighbors, index._layer(l).neighbors) for l in range(index.layer_count()))
+        del h
+        comm_model = st["all_gather_bytes"] * (w - 1) / w / 50e9
+        host = (st["all_gather_calls"] + st["all_reduce_calls"]) * 30e-6
+        crit = st["seconds_sharded"] + st["seconds_replicated"] + st["seconds_comm"] + comm_model + host
+        out = {"world": w, "emulated_on_one_gpu": True, "identical_to_single_gpu_build": bool(same),
+               "single_gpu_build_s": round(single_s, 3), "rank0_critical_path_s": round(crit, 3),
+               "modelled_speedup_at_8": round(single_s / crit, 2),
+               "rank0_seconds": {"sharded_phases": round(st["seconds_sharded"], 3), "replicated_phases": round(st["seconds_replicated"], 3),
+                                 "reassembly": round(st["seconds_comm"], 4), "all_gather_model_one_link_50GBs": round(comm_model, 4),
+                                 "host_per_collective_30us": round(host, 4)},
+               "rank0_seconds_by_phase": {k: round(v, 3) for k, v in st["seconds_by_phase"].items()},
+               "all_gather_GB_received_per_rank": round(st["all_gather_bytes"] / 1e9, 3),
+               "collectives": st["all_gather_calls"] + st["all_reduce_calls"], "phases": st["phases"],
+               "phases_too_short_to_split": st["phases_whole"],
+               "note": "a model, not a measurement of 8 GPUs: the transport is the only part of phnsw_build_sharded that did not "
+                       "run; profiles/r03/ holds the same for 10M x 768 (BASELINE config 4)"}
+        log("sharded build, emulated world of 8: rank 0 %.2f s vs %.2f s single GPU = %.2fx (identical graph: %s)" % (
+            crit, single_s, single_s / crit, same))
+        return out
+    except Exception as exc:
+        log("sharded build model failed: %r" % (exc,))
+        return {"error": repr(exc)}
 
 
 def cpu_baseline(args, log, ph, torch, store, index, qstore, run, sp, gt, recall_at_10, dev):
@@ -702,7 +811,17 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
                            "results; %d queries per batch (search + re-rank, wall time)" % (args.n, args.dim, m_, m_, nq),
                "build_s": round(pq_build, 1), "recall_target_met": best.pop("met"), **best,
                "algorithmic_bytes_per_query": round(bq),
-               "algorithmic_gbs": round(best["queries_per_s"] * bq / 1e9, 1), "cells": cells}
+               "algorithmic_gbs": round(best["queries_per_s"] * bq / 1e9, 1), "cells": cells,
+               "roofline": {"bound": "hbm", "achieved": round(best["queries_per_s"] * bq / 1e9, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(best["queries_per_s"] * bq / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                            "kernel": "ph_search_kernel_pqr<8, %d> (+ ph_pq_rerank_kernel)" % m_,
+                            "limiter": "not memory: the per-hop dependency chain at 2 waves per SIMD (the query's 96-row 8-bit table "
+                                       "occupies 96 of a wave's 256 registers) -- neighbour row, visited test-and-set beside the "
+                                       "code rows, 96 ds_bpermute look-ups (one crossbar pass serves one table row whatever the "
+                                       "number of candidates), queue merge; counters in profiles/r03/pq_kernel_summary.json",
+                            "algorithmic_definition": "evaluations x m code bytes + hops x W x 4 B + re-ranked rows x row bytes"},
+               "vs_f32_note": "PQ trades 32x less vector memory (96 B instead of 3 072 B per vector) for ~1.4x the hops at equal "
+                              "recall; on this part a wave streams a 3 KB row faster than 96 dependent table look-ups issue"}
         del qh, pids, pd_
         return out
     except Exception as exc:
@@ -819,10 +938,12 @@ def pmc_passes(args, tmp, line):
                      "l2_hit_rate": round(hit / (hit + miss), 3) if hit + miss else None})
         tot_r, tot_w = tot_r + rb, tot_w + wb
         tot_dram += db or 0.0
-    out["traffic"] = round(tot_r + tot_w)
-    out["traffic_read"] = round(tot_r)
-    out["traffic_write"] = round(tot_w)
-    out["traffic_dram_read"] = round(tot_dram) if dram_bytes_per_req else None
+    srch = [x for x in disp if "ph_search_kernel" in x["kernel"]]
+    out["traffic"] = round(sum(x["read_GB"] + x["write_GB"] for x in srch) * 1e9)  # the search kernel alone
+    out["traffic_read"] = round(sum(x["read_GB"] for x in srch) * 1e9)
+    out["traffic_write"] = round(sum(x["write_GB"] for x in srch) * 1e9)
+    out["traffic_dram_read"] = round(sum((x["dram_read_GB"] or 0.0) for x in srch) * 1e9) if dram_bytes_per_req else None
+    out["traffic_whole_launch"] = round(tot_r + tot_w)
     out["pmc_dispatches"] = disp
     out["calibration"] = {"kernel": "ph_distance_batch_kernel (K1): distinct rows read once, 16 B per lane",
                           "known_read_bytes": known, "candidates": {k: round(v) for k, v in cands.items()},
@@ -834,6 +955,77 @@ def pmc_passes(args, tmp, line):
     out["traffic_source"] = "rocprofv3 --pmc passes of this run (%s), child processes of bench.py on the same index: %s" % (
         ", ".join("+".join(c) for _, c in PMC_PASSES), "mean of %d launches" % PMC_MEASURED)
     return out
+
+
+def pmc_build_child(args):
+    """runs under `rocprofv3 --pmc ... --kernel-trace`: one build of the headline index"""
+    import numpy as np
+    import torch
+    import parallel_hnsw_amd as ph
+    meta = json.load(open(os.path.join(args.index_dir, "bench_meta.json")))
+    torch.cuda.set_device(0)
+    store = make_store(ph, meta["kind"], meta["n"], meta["dim"], 0, 0)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    h = ph.Hnsw.generate(store, np.arange(store.n, dtype=np.uint64), ph.BuildParameters())
+    torch.cuda.synchronize()
+    print(json.dumps({"build_s_under_profiler": round(time.time() - t0, 2), "layers": h.layer_count()}), flush=True)
+
+
+BUILD_FAMILIES = [("ph_search_kernel_dense", "K2 dense-layer walk (split descents)"),
+                  ("ph_search_kernel_lat", "K2 small batches (latency form)"),
+                  ("ph_search_kernel", "K2 greedy search: link rounds, discover_unreachable, recall samples, initial partitions"),
+                  ("ph_tiny_", "dense top-layer tables (prep, pack, MFMA / VALU table)"),
+                  ("ph_seed_rows", "K3 seeding"), ("ph_merge_rows", "K5 row merges"), ("ph_row_dist", "occupant distances"),
+                  ("ph_gemm_nt_mfma", "anchor GEMM (cells of the locality schedule)"), ("ph_topk", "anchor top-1"),
+                  ("ph_cover", "promotion thinning"), ("rocprim", "rocPRIM sorts / scans"), ("ph_synth", "dataset generation (not build)")]
+
+
+def pmc_build_pass(args, tmp):
+    """memory-side read bytes and GPU milliseconds per kernel family of one index build (rocprofv3 --pmc + --kernel-trace)"""
+    d = os.path.join(tmp, "pmc_build")
+    counters = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum"]
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "b", "--",
+                                               sys.executable, os.path.abspath(__file__), "--role", "pmc_build", "--index-dir", tmp]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError("rocprofv3 build pass failed (%d): %s" % (r.returncode, r.stderr[-600:]))
+    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    by = read_counter_csv(d)
+    fam = {}
+
+    def family(name):
+        for key, label in BUILD_FAMILIES:
+            if key in name:
+                return label
+        return "other"
+
+    for i, (name, c) in by.items():
+        f = fam.setdefault(family(name), {"dispatches": 0, "read_bytes": 0.0, "ms": 0.0})
+        rd, r32, r128 = c.get("TCC_EA0_RDREQ_sum", 0.0), c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        f["read_bytes"] += 32 * r32 + 128 * r128 + 64 * (rd - r32 - r128)
+        f["dispatches"] += 1
+    for fn in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            f = fam.setdefault(family(row["Kernel_Name"]), {"dispatches": 0, "read_bytes": 0.0, "ms": 0.0})
+            f["ms"] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+    out = []
+    for label, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        if label.startswith("dataset generation"):
+            continue
+        e = {"kernels": label, "dispatches": f["dispatches"], "gpu_ms": round(f["ms"], 2), "read_GB": round(f["read_bytes"] / 1e9, 2)}
+        if f["ms"] > 0:
+            e["read_gbs"] = round(f["read_bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
+            e["frac_of_hbm_peak"] = round(e["read_gbs"] / HBM_PEAK_GBS, 4)
+        out.append(e)
+    print("[bench] build pmc pass: %d dispatches, %.0f s" % (len(by), time.time() - t0), file=sys.stderr, flush=True)
+    return {"source": "rocprofv3 --pmc %s --kernel-trace over one build of the headline index (a child process; counters serialise "
+                      "the kernels: milliseconds are per kernel, not wall)" % " ".join(counters),
+            "build_s_under_profiler": info["build_s_under_profiler"],
+            "read_bytes_formula": "32 B x RDREQ_32B + 128 B x RDREQ_128B + 64 B x the rest (the formula the search passes calibrate)",
+            "families": out}
 
 
 # --------------------------------------------------------------------------------------- driver
@@ -892,6 +1084,12 @@ def driver(args):
                 print("[bench] pmc passes failed: %r" % (exc,), file=sys.stderr, flush=True)
                 roof["pmc_error"] = repr(exc)
         finish_roofline(roof, line)
+        if want_pmc and line.get("build_roofline") is not None:
+            try:
+                line["build_roofline"]["kernels"] = pmc_build_pass(args, tmp)
+            except Exception as exc:
+                print("[bench] build pmc pass failed: %r" % (exc,), file=sys.stderr, flush=True)
+                line["build_roofline"]["kernels_error"] = repr(exc)
         print(json.dumps(line), flush=True)
         return 0
     finally:
@@ -899,19 +1097,21 @@ def driver(args):
 
 
 def finish_roofline(roof, line):
-    """achieved / frac from the measured (or, failing that, replayed) memory-side bytes of one launch"""
+    """traffic_ratio and the counter-side rates from the measured (or, failing that, replayed) memory-side bytes of the
+    search kernel; `achieved` / `frac` (algorithmic bytes / the kernel's time) were set by the worker"""
     if roof.get("traffic") is None:
         replay_profile(roof, line)
     if roof.get("traffic") is not None:
         ktime = roof["kernel_ms"] * 1e-3
-        roof["achieved"] = round(roof["traffic"] / ktime / 1e9, 1)
-        roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-        roof["reuse_factor"] = round(roof["algorithmic_bytes_per_launch"] / roof["traffic"], 3)
+        roof["traffic_gbs"] = round(roof["traffic"] / ktime / 1e9, 1)
+        roof["traffic_frac"] = round(roof["traffic_gbs"] / HBM_PEAK_GBS, 4)
+        roof["traffic_ratio"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
         if roof.get("traffic_dram_read") is not None:
             roof["dram_read_gbs"] = round(roof["traffic_dram_read"] / ktime / 1e9, 1)
-        roof["note"] = ("achieved = bytes measured on the L2's memory side (HBM + Infinity Cache) for one launch / "
-                        "kernel_ms; algorithmic bytes (N_dist x row bytes + ..., SURVEY 8d) / traffic = reuse_factor: "
-                        "rows shared through L2 and the evaluations the dense top-layer tables serve")
+        roof["note"] = ("frac = achieved / peak with achieved = algorithmic bytes of ph_search_kernel / its own time; traffic = "
+                        "bytes measured on the L2's memory side (HBM + Infinity Cache) for the same kernel; traffic_ratio = "
+                        "traffic / algorithmic bytes (> 1: visited-bit atomics, spill lists, vec2node, table rows read from "
+                        "global memory; < 1 would mean rows shared through L2)")
 
 
 def replay_profile(roof, line):
@@ -925,9 +1125,9 @@ def replay_profile(roof, line):
         c = line["config"]
         same = (w.get("dataset_text") == c["dataset"] and w.get("nq") == line["queries_per_step_per_gpu"] and
                 w.get("ef") == c["number_of_candidates"] and w.get("probe_depth") == c["probe_depth"])
-        if same and pm.get("source_hash") == roof["source_hash"] and pm.get("reuse_factor"):
-            roof["traffic"] = round(roof["algorithmic_bytes_per_launch"] / pm["reuse_factor"])
-            roof["traffic_source"] = "REPLAYED from %s (same workload, same kernel sources %s): algorithmic bytes of this run / its reuse_factor" % (
+        if same and pm.get("source_hash") == roof["source_hash"] and pm.get("traffic_ratio"):
+            roof["traffic"] = round(roof["algorithmic_bytes_per_launch"] * pm["traffic_ratio"])
+            roof["traffic_source"] = "REPLAYED from %s (same workload, same kernel sources %s): algorithmic bytes of this run x its traffic_ratio" % (
                 os.path.relpath(f, ROOT), pm["source_hash"])
             return
     roof["traffic_source"] = None
@@ -940,6 +1140,8 @@ def main():
         worker(args)
     elif role == "pmc":
         pmc_child(args)
+    elif role == "pmc_build":
+        pmc_build_child(args)
     else:
         sys.exit(driver(args))
 

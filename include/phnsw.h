@@ -217,10 +217,14 @@ int phnsw_last_search_kernel_ms(const phnsw_index *ix, float *ms);
 /* the same descent dispatch by dispatch (measurement only): entry 0 = the dense-top-layer tile pass
  * (csrc/tiny.hip; layers 0..0), then one entry per launch of the search kernel: layers
  * [layer_lo, layer_hi), milliseconds, distance evaluations and hops.  *count = entries available;
- * at most cap are written; any output array may be NULL. */
+ * at most cap are written; any output array may be NULL.  A query list longer than the dense table holds
+ * (4 GiB by default: ~145 000 queries at 1M x 768) runs in chunks; times and counters then describe the LAST chunk. */
 int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap, uint32_t *count, float *ms,
                                  uint64_t *n_dist, uint64_t *n_hops, uint32_t *layer_lo,
                                  uint32_t *layer_hi);
+/* per entry of phnsw_last_search_dispatches: how many of the launch's distance evaluations were served by the
+ * dense tables (measurement only); n_dist - n_table are gathered rows, the bytes an HBM roofline counts */
+int phnsw_last_search_table_evals(const phnsw_index *ix, uint32_t cap, uint32_t *count, uint64_t *n_table);
 /* how a search with this number_of_candidates treats the leading layers (measurement only): *layers =
  * how many of them are walked through the dense distance table (csrc/tiny.hip), *nodes = nodes of
  * the largest of them (the table's width), *matrix_cores = 1 when the table is built by the MFMA

@@ -128,6 +128,7 @@ SYMBOLS = {
     "phnsw_index_counters": (_i32, [_vp, _vp, _vp]),
     "phnsw_last_search_kernel_ms": (_i32, [_vp, C.POINTER(_f32)]),
     "phnsw_last_search_dispatches": (_i32, [_vp, _u32, C.POINTER(_u32), _vp, _vp, _vp, _vp, _vp]),
+    "phnsw_last_search_table_evals": (_i32, [_vp, _u32, C.POINTER(_u32), _vp]),
     "phnsw_dense_top_layers": (_i32, [_vp, _u64, C.POINTER(_u32), C.POINTER(_u64), C.POINTER(_u32)]),
     "phnsw_index_create": (_i32, [_vp, C.POINTER(BuildParams), _pp]),
     "phnsw_build_plan": (_i32, [_vp, _u64, C.POINTER(BuildParams), _vp, _vp, _u32, C.POINTER(_u32)]),

@@ -625,6 +625,8 @@ static uint32_t default_ovf_cap(uint32_t ef) { return ph_default_ovf_cap(ef); }
 
 static std::atomic<uint64_t> g_two_launch_count{0};  // tests check that the split path really ran
 extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count.load(); }
+// chunks of the last descent on this index (phnsw_last_search_dispatches then describes the last one)
+extern "C" uint32_t phnsw_debug_last_search_chunks(const phnsw_index *ix) { return ix ? ix->ws[ix->ws_last].n_chunks : 0; }
 
 // enqueue one search launch; caller owns all device buffers
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
@@ -752,12 +754,16 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
       if (b.out_hit) b.out_hit += c0;
       b.first_node += (uint32_t)c0;
     }
+    ws.n_chunks = (uint32_t)(c0 / chunk) + 1;
+    PH_HIP(hipEventRecord(ws.evc, stream));  // the dispatch record describes ONE chunk (the last): its clock ...
+    if (c0) PH_HIP(hipMemsetAsync(ws.dtotals, 0, sizeof(unsigned long long) * 3 * PH_MAX_DISPATCH, stream));  // ... and counters
     rc = ph_tiny_prepare(ix, ws, b, T, stream);
     if (rc) return rc;
     ws.d_tiny = b.tiny_layers != 0;
     PH_HIP(hipEventRecord(ws.evd[0], stream));
     if (!split) {
       b.launch_totals = ws.dtotals;
+      b.launch_tab = ws.dtotals + 2 * PH_MAX_DISPATCH;
       rc = ph_search_launch(ix, ws, b, stream, last_chunk);
       if (rc) return rc;
       PH_HIP(hipEventRecord(ws.evd[1], stream));
@@ -793,6 +799,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
       p.out_key = last ? nullptr : ws.okey;
       p.key_pos = last ? nullptr : ix->layers[hi - 1].pos;
       p.launch_totals = ws.dtotals + 2 * di;
+      p.launch_tab = ws.dtotals + 2 * PH_MAX_DISPATCH + di;
       rc = ph_search_launch(ix, ws, p, stream, last && last_chunk);
       if (!rc && !last) rc = ph_workspace_order_sort(ws, b.nq, stream);
       if (rc) return rc;
@@ -887,13 +894,35 @@ extern "C" int phnsw_last_search_dispatches(const phnsw_index *ix, uint32_t cap,
   *count = n;
   for (uint32_t i = 0; i < n && i < cap; i++) {
     float t = 0.f;
-    PH_HIP(hipEventElapsedTime(&t, i == 0 ? ws.ev0 : ws.evd[i - 1], ws.evd[i]));
+    PH_HIP(hipEventElapsedTime(&t, i == 0 ? ws.evc : ws.evd[i - 1], ws.evd[i]));
     if (ms) ms[i] = t;
     if (n_dist) n_dist[i] = i ? h[2 * (i - 1)] : 0;
     if (n_hops) n_hops[i] = i ? h[2 * (i - 1) + 1] : 0;
     if (layer_lo) layer_lo[i] = i ? ws.d_lo[i - 1] : 0;
     if (layer_hi) layer_hi[i] = i ? ws.d_hi[i - 1] : 0;
   }
+  return 0;
+} catch (...) { return ph_caught(); }
+
+// of each search launch's distance evaluations, those served by the dense tables (entry 0, the table pass, is 0):
+// n_dist - n_table are the gathered rows -- what the HBM roofline of a launch is computed from
+extern "C" int phnsw_last_search_table_evals(const phnsw_index *ix, uint32_t cap, uint32_t *count, uint64_t *n_table) try {
+  if (!ix || !count) return PHNSW_E_INVALID;
+  phnsw_index *mix = const_cast<phnsw_index *>(ix);
+  std::lock_guard<std::mutex> g(mix->ws_mutex);
+  PhWorkspace &ws = mix->ws[mix->ws_last];
+  if (!ws.timed) {
+    ph_set_error("no search has been launched on this index");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(ix->store->device));
+  PH_HIP(hipEventSynchronize(ws.ev1));
+  unsigned long long h[PH_MAX_DISPATCH];
+  PH_HIP(hipMemcpy(h, ws.dtotals + 2 * PH_MAX_DISPATCH, sizeof(h), hipMemcpyDeviceToHost));
+  const uint32_t n = ws.n_dispatch + 1;
+  *count = n;
+  for (uint32_t i = 0; i < n && i < cap; i++)
+    if (n_table) n_table[i] = i ? h[i - 1] : 0;
   return 0;
 } catch (...) { return ph_caught(); }
 

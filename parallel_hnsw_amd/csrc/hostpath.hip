@@ -184,7 +184,11 @@ void plan_chunks(uint64_t nq, std::vector<uint64_t> &bounds) {
   uint64_t at = std::min(first, nq);
   bounds.push_back(at);
   const uint64_t rest = nq - at;
-  const uint64_t pieces = std::max<uint64_t>(1, (rest + piece - 1) / piece);
+  uint64_t pieces = std::max<uint64_t>(1, (rest + piece - 1) / piece);
+  // very long lists: pieces of at least PH_TWO_LAUNCH_MIN queries, so that each still descends in launches of
+  // its own per large layer, its queries ordered by where they landed (api.hip; the upload of 100 MB per piece
+  // hides behind the previous piece's search all the same)
+  if (nq >= 2 * (uint64_t)PH_TWO_LAUNCH_MIN && !getenv("PHNSW_HOST_CHUNKS")) pieces = std::max<uint64_t>(1, rest / PH_TWO_LAUNCH_MIN);
   for (uint64_t p = 1; p <= pieces; p++) bounds.push_back(at + rest * p / pieces);
 }
 

@@ -104,6 +104,7 @@ struct PhWorkspace {
   uint32_t n_slots = 0;
   uint32_t *counter = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evc = nullptr;  // start of the last chunk of the descent (== ev0 when the list ran in one piece)
   bool timed = false;
   void *pq_tables = nullptr;  // n_slots x table bytes (PQ stores)
   size_t pq_tables_bytes = 0;
@@ -129,8 +130,11 @@ struct PhWorkspace {
   // per-dispatch bookkeeping of the last descent (phnsw_last_search_dispatches): evd[0] closes the
   // dense-top-layer kernels, evd[1 + i] search launch i; dtotals[i] = {distance evaluations, hops}
   hipEvent_t evd[PH_MAX_DISPATCH + 1] = {};
-  unsigned long long *dtotals = nullptr;  // device [PH_MAX_DISPATCH][2]
+  unsigned long long *dtotals = nullptr;  // device [PH_MAX_DISPATCH][2], then [PH_MAX_DISPATCH] table-served evaluations
   uint32_t n_dispatch = 0;
+  uint32_t n_chunks = 0;  // chunks of the last descent (a query list longer than the dense table holds): the per-dispatch
+                          // figures then describe the LAST chunk, times and counters alike
+  int cus = 0;            // compute units of the workspace's device
   uint32_t d_lo[PH_MAX_DISPATCH] = {}, d_hi[PH_MAX_DISPATCH] = {};
   bool d_tiny = false;
 };
@@ -186,6 +190,7 @@ struct PhSearchArgs {
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
   unsigned long long *totals;   // nullable: [2] running sums of distance evaluations / hops (all launches)
   unsigned long long *launch_totals;  // nullable: [2] the same for this launch alone
+  unsigned long long *launch_tab;     // nullable: of this launch's evaluations, those the dense tables served
   void *pq_tables;              // PQ store: per-wave lookup-table slots in global memory (DistPQG)
   uint32_t pq_table_bytes;      // bytes per slot
   uint32_t layer_lo, layer_hi;  // layers of this launch (0, 0 = all); see search.hip

@@ -146,6 +146,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     const uint32_t excl = a.exclude ? a.exclude[q] : PH_EMPTY32;
     uint32_t n_dist = 0, n_hops = 0, err = ST_OK;
     uint32_t index_distance = 0xFFFFFFFFu;  // usize::MAX until a layer has run  search.rs:112
+    uint32_t n_tab = 0;  // of n_dist: evaluations served by the dense tables (measurement: the rest are gathered rows)
     uint32_t n_dist0 = 0, n_hops0 = 0;  // counters a split descent brought in from its earlier launches
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
@@ -370,6 +371,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         const uint64_t fm = __ballot(fresh);
         const uint32_t m = __popcll(fm);
         n_dist += m;
+        if (tl) n_tab += m;
 #ifdef PH_CELL_PROBE
         if (probing) {
           uint32_t dd = 0xFFFFFFFFu;
@@ -752,6 +754,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     if (lane == 0 && a.launch_totals) {
       atomicAdd(&a.launch_totals[0], (unsigned long long)(n_dist - n_dist0));
       atomicAdd(&a.launch_totals[1], (unsigned long long)(n_hops - n_hops0));
+      if (a.launch_tab && n_tab) atomicAdd(a.launch_tab, (unsigned long long)n_tab);
     }
     if constexpr (INSTR)
       if (lane == 0) a.out_index[q] = index_distance;
@@ -917,6 +920,7 @@ void ph_workspace_free(PhWorkspace &ws) {
   if (ws.pq_tables) hipFree(ws.pq_tables);
   if (ws.ev0) hipEventDestroy(ws.ev0);
   if (ws.ev1) hipEventDestroy(ws.ev1);
+  if (ws.evc) hipEventDestroy(ws.evc);
   for (auto &e : ws.evd)
     if (e) hipEventDestroy(e);
   if (ws.dtotals) hipFree(ws.dtotals);
@@ -944,8 +948,9 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
     PH_HIP(hipMalloc(&ws.counter, 512));  // 8 work counters, 64 B apart
     PH_HIP(hipEventCreate(&ws.ev0));
     PH_HIP(hipEventCreate(&ws.ev1));
+    PH_HIP(hipEventCreate(&ws.evc));
     for (auto &e : ws.evd) PH_HIP(hipEventCreate(&e));
-    PH_HIP(hipMalloc(&ws.dtotals, sizeof(unsigned long long) * 2 * PH_MAX_DISPATCH));
+    PH_HIP(hipMalloc(&ws.dtotals, sizeof(unsigned long long) * 3 * PH_MAX_DISPATCH));
   }
   if (ws.n_slots < slots || ws.visited_words < words) {
     if (ws.visited) PH_HIP(hipFree(ws.visited));
@@ -981,7 +986,7 @@ int ph_workspace_ensure(const phnsw_index *ix, PhWorkspace &ws, uint32_t ef, uin
 int ph_search_begin(PhWorkspace &ws, hipStream_t stream) {
   if (ws.timed) PH_HIP(hipStreamWaitEvent(stream, ws.ev1, 0));
   PH_HIP(hipEventRecord(ws.ev0, stream));
-  PH_HIP(hipMemsetAsync(ws.dtotals, 0, sizeof(unsigned long long) * 2 * PH_MAX_DISPATCH, stream));
+  PH_HIP(hipMemsetAsync(ws.dtotals, 0, sizeof(unsigned long long) * 3 * PH_MAX_DISPATCH, stream));
   ws.n_dispatch = 0;
   ws.d_tiny = false;
   return 0;
@@ -1007,14 +1012,12 @@ static int search_launch_dense(PhWorkspace &ws, PhSearchArgs &a, hipStream_t str
     return PHNSW_E_UNSUPPORTED;
   }
   const size_t lds = lds_bytes(capc, ph_tiny_lds_bytes(a));
-  static int cus = 0;
-  if (!cus) {
+  if (!ws.cus) {  // per workspace, hence per index and device (a process may drive several devices)
     int dev = 0;
-    hipDeviceProp_t prop;
     PH_HIP(hipGetDevice(&dev));
-    PH_HIP(hipGetDeviceProperties(&prop, dev));
-    cus = prop.multiProcessorCount;
+    PH_HIP(hipDeviceGetAttribute(&ws.cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
+  const int cus = ws.cus;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
   per_cu = std::min(per_cu, 32);

@@ -431,11 +431,15 @@ uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t 
 
 static uint32_t tiny_stride_of(uint32_t n) { return (n + 63u) / 64u * 64u; }
 
-// the table of one launch is kept below 4 GiB; longer query lists run in chunks (api.hip)
+// the table of one launch is kept below 4 GiB (PHNSW_TINY_TABLE_BYTES overrides: tests, small devices); longer
+// query lists run in chunks (api.hip)
 uint64_t ph_tiny_max_positions(const phnsw_index *ix, uint32_t n_layers, uint32_t ef) {
   uint32_t T = ph_tiny_layer_count(ix, n_layers, ef);
   if (!T) return 0;
-  return (4ull << 30) / ((uint64_t)tiny_stride_of(ix->layers[T - 1].n_nodes) * 4u);
+  uint64_t budget = 4ull << 30;
+  if (const char *e = getenv("PHNSW_TINY_TABLE_BYTES"))
+    if (atoll(e) > 0) budget = (uint64_t)atoll(e);
+  return std::max<uint64_t>(64, budget / ((uint64_t)tiny_stride_of(ix->layers[T - 1].n_nodes) * 4u));
 }
 
 size_t ph_tiny_lds_bytes(const PhSearchArgs &a) {
@@ -472,9 +476,14 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
     a.tiny_off[l] = (uint32_t)nbr_words;
     nbr_words += (size_t)tn * a.layers[l].W;
   }
-  PH_HIP(grow(&ws.tiny_d, &ws.tiny_d_bytes, std::max<size_t>((size_t)npos * stride * 4u, 1u << 20)));
-  PH_HIP(grow(&ws.tiny_nbr, &ws.tiny_nbr_bytes, nbr_words * 4u));
-  PH_HIP(grow(&ws.tiny_member, &ws.tiny_member_bytes, (size_t)(PH_TINY_MAX_NODES + 1u) * 4u));
+  // the table is an accelerator, never a requirement: when the device cannot spare it the launch simply walks
+  // every layer on the per-hop path (same results)
+  if (grow(&ws.tiny_d, &ws.tiny_d_bytes, std::max<size_t>((size_t)npos * stride * 4u, 1u << 20)) != hipSuccess ||
+      grow(&ws.tiny_nbr, &ws.tiny_nbr_bytes, nbr_words * 4u) != hipSuccess ||
+      grow(&ws.tiny_member, &ws.tiny_member_bytes, (size_t)(PH_TINY_MAX_NODES + 1u) * 4u) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
   p.nbr = ws.tiny_nbr;
   p.member = ws.tiny_member;
   PH_HIP(hipMemsetAsync(ws.tiny_nbr, 0xFF, nbr_words * 4u, stream));
@@ -504,8 +513,11 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
   if (mfma) {
     const uint32_t qtiles = (npos + 63u) / 64u, ntiles = (tn + 63u) / 64u;
     const size_t row_bytes = (size_t)nv * 64u * sizeof(float4);
-    PH_HIP(grow(&ws.tiny_pq, &ws.tiny_pq_bytes, (size_t)qtiles * 64u * row_bytes));
-    PH_HIP(grow(&ws.tiny_pn, &ws.tiny_pn_bytes, (size_t)ntiles * 64u * row_bytes));
+    if (grow(&ws.tiny_pq, &ws.tiny_pq_bytes, (size_t)qtiles * 64u * row_bytes) != hipSuccess ||
+        grow(&ws.tiny_pn, &ws.tiny_pn_bytes, (size_t)ntiles * 64u * row_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
     PhTinyPackArgs k;
     memset(&k, 0, sizeof(k));
     k.vecs = a.dist.vecs;

@@ -629,16 +629,19 @@ class Hnsw:
         return ms.value
 
     def dispatches(self):
-        """the last descent dispatch by dispatch: [{"layers": (lo, hi), "ms", "n_dist", "n_hops"}];
-        entry 0 is the dense-top-layer tile pass (layers (0, 0))"""
+        """the last descent dispatch by dispatch: [{"layers": (lo, hi), "ms", "n_dist", "n_hops", "n_table"}];
+        entry 0 is the dense-top-layer tile pass (layers (0, 0)); n_table of n_dist evaluations were table look-ups"""
         cap = 32
         cnt = C.c_uint32()
         ms = np.zeros(cap, dtype=np.float32)
         nd, nh = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
         lo, hi = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
         check(lib().phnsw_last_search_dispatches(self._h, cap, C.byref(cnt), _p(ms), _p(nd), _p(nh), _p(lo), _p(hi)))
-        return [{"layers": (int(lo[i]), int(hi[i])), "ms": float(ms[i]), "n_dist": int(nd[i]), "n_hops": int(nh[i])}
-                for i in range(min(cap, cnt.value))]
+        nt = np.zeros(cap, dtype=np.uint64)
+        c2 = C.c_uint32()
+        check(lib().phnsw_last_search_table_evals(self._h, cap, C.byref(c2), _p(nt)))
+        return [{"layers": (int(lo[i]), int(hi[i])), "ms": float(ms[i]), "n_dist": int(nd[i]), "n_hops": int(nh[i]),
+                 "n_table": int(nt[i])} for i in range(min(cap, cnt.value))]
 
     def dense_top_layers(self, number_of_candidates):
         """(layers walked through the dense distance table, nodes of the largest, built on the matrix cores?)"""

@@ -236,3 +236,34 @@ def test_not_nested_layers_with_a_dense_first_launch():
         r2 = h2.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2), stats=True)
         with no_dense_split():
             same(r2, h2.search_batch(queries=q, sp=ph.SearchParameters(8, 8, 2), stats=True))
+
+
+def test_chunked_descents_equal_unchunked(monkeypatch):
+    """a query list longer than the dense table holds runs in consecutive chunks of the list (api.hip): with the table
+    budget cut to a few hundred rows (PHNSW_TINY_TABLE_BYTES) the results -- ids, distance bits, lengths, counters --
+    equal the one-piece run, for plain lists, for lists with a processing order (build rounds) and through the host
+    path; the smallest budget still runs (tables of 64 rows)"""
+    import ctypes as C
+    n, dim = 30000, 128
+    store = ph.VectorStore.synthetic(n, dim, seed=42)
+    h = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters(seed=3, max_link_rounds=1))
+    q = ph.VectorStore.synthetic(2000, dim, seed=42, first=2 ** 32).read()
+    sp = ph.SearchParameters(64, 64, 2)
+    whole = h.search_batch(queries=q, sp=sp, stats=True)
+    qid = np.arange(0, n, 11, dtype=np.uint64)
+    swhole = h.search_batch(qids=qid, sp=sp, exclude=qid, stats=True)
+    L = ph.lib()
+    L.phnsw_debug_last_search_chunks.restype = C.c_uint32
+    L.phnsw_debug_last_search_chunks.argtypes = [C.c_void_p]
+    assert L.phnsw_debug_last_search_chunks(h._h) == 1
+    stride = (h._layer(2).node_count() + 63) // 64 * 64   # the table layer of this shape
+    monkeypatch.setenv("PHNSW_TINY_TABLE_BYTES", str(300 * stride * 4))
+    same(h.search_batch(queries=q, sp=sp, stats=True), whole)
+    assert L.phnsw_debug_last_search_chunks(h._h) >= 5
+    same(h.search_batch(qids=qid, sp=sp, exclude=qid, stats=True), swhole)
+    # a build (its rounds carry a processing order and run Stored queries through the same chunk loop) is unchanged
+    g = ph.Hnsw.generate(store, np.arange(n, dtype=np.uint64), ph.BuildParameters(seed=3, max_link_rounds=1))
+    for l in range(h.layer_count()):
+        np.testing.assert_array_equal(g._layer(l).neighbors, h._layer(l).neighbors)
+    monkeypatch.setenv("PHNSW_TINY_TABLE_BYTES", "1")
+    same(h.search_batch(queries=q[:500], sp=sp, stats=True), [x[:500] for x in whole])
