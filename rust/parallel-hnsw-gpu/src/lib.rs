@@ -133,6 +133,48 @@ unsafe extern "C" fn progress_trampoline(user: *mut c_void, phase: *const c_char
 }
 
 /// `Hnsw<GpuComparator>` whose layers live on the GPU.
+/// The collective seam of the sharded build (`phnsw_comm`): the library's own RCCL transport over xGMI -- rank 0
+/// makes the 128-byte id, the host hands it to the other ranks (a file, MPI, a socket), every rank creates its
+/// communicator on its own GPU -- or any transport the host supplies as two callbacks.
+pub struct ShardComm {
+    owned: *mut sys::phnsw_comm,
+    custom: Option<Box<sys::phnsw_comm>>,
+}
+unsafe impl Send for ShardComm {}
+impl ShardComm {
+    pub fn rccl_unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        check(unsafe { sys::phnsw_comm_rccl_unique_id(id.as_mut_ptr()) });
+        id
+    }
+    pub fn rccl(id: &[u8; 128], rank: u32, world: u32, device: i32) -> Self {
+        let mut c = std::ptr::null_mut();
+        check(unsafe { sys::phnsw_comm_rccl_create(id.as_ptr(), rank, world, device, &mut c) });
+        ShardComm { owned: c, custom: None }
+    }
+    /// a transport of the host's own (MPI, ...): see `phnsw_comm` in include/phnsw.h for the two callbacks
+    pub fn custom(c: sys::phnsw_comm) -> Self {
+        ShardComm { owned: std::ptr::null_mut(), custom: Some(Box::new(c)) }
+    }
+    /// every rank calls it: a known pattern through the all-gather and the all-reduce, verified on every rank
+    pub fn selftest(&self, bytes: u64) {
+        check(unsafe { sys::phnsw_comm_selftest(self.as_ptr(), bytes) });
+    }
+    fn as_ptr(&self) -> *const sys::phnsw_comm {
+        match &self.custom {
+            Some(b) => &**b as *const sys::phnsw_comm,
+            None => self.owned as *const sys::phnsw_comm,
+        }
+    }
+}
+impl Drop for ShardComm {
+    fn drop(&mut self) {
+        if !self.owned.is_null() {
+            unsafe { sys::phnsw_comm_destroy(self.owned) }
+        }
+    }
+}
+
 pub struct GpuHnsw {
     ix: *mut sys::phnsw_index,
     comparator: GpuComparator,
@@ -158,6 +200,23 @@ impl GpuHnsw {
                              &mut monitor as *mut &mut dyn ProgressMonitor as *mut c_void, &mut ix)
         });
         GpuHnsw { ix, comparator: c, build_parameters: bp }
+    }
+
+    /// `Hnsw::generate` with every per-node phase split over the GPUs of one node (BASELINE config 4): one process
+    /// per GPU, every rank calls this with the same vectors, ids and parameters and ends with the same index
+    /// (`phnsw_build_sharded`: node ranges per round, all-gather of the per-node results, lib.rs:1097-1153)
+    pub fn generate_sharded(c: GpuComparator, vs: Vec<VectorId>, bp: BuildParameters, comm: &ShardComm,
+                            progress: &mut dyn ProgressMonitor) -> (Self, sys::phnsw_sharded_stats) {
+        let raw: Vec<u64> = vs.iter().map(|v| v.0 as u64).collect();
+        let mut ix = std::ptr::null_mut();
+        let mut stats = sys::phnsw_sharded_stats::default();
+        let mut monitor: &mut dyn ProgressMonitor = progress;
+        check(unsafe {
+            sys::phnsw_build_sharded(c.store.0, raw.as_ptr(), raw.len() as u64, &bp_c(bp, 0), comm.as_ptr(),
+                                     Some(progress_trampoline), &mut monitor as *mut &mut dyn ProgressMonitor as *mut c_void,
+                                     &mut ix, &mut stats)
+        });
+        (GpuHnsw { ix, comparator: c, build_parameters: bp }, stats)
     }
 
     /// adopt the layers of an `Hnsw` the crate built or deserialised (top first, lib.rs:587)
@@ -251,6 +310,45 @@ impl GpuHnsw {
         check(rc);
         (0..nq).map(|q| (0..len[q] as usize).map(|k| (VectorId(ids[q * ef + k] as usize), d[q * ef + k])).collect())
                .collect()
+    }
+
+    /// `search(v, sp)` for a batch of raw queries keeping the best `k` of each: the truncation the crate's callers do
+    /// themselves (lib.rs:1118) happens on the device, before the transfer (`phnsw_search_batch_topk`)
+    pub fn search_many_topk(&self, queries: &[Vec<f32>], sp: SearchParameters, k: usize) -> Vec<Vec<(VectorId, f32)>> {
+        let nq = queries.len();
+        let psp = sp_c(sp);
+        let mut q: Vec<f32> = Vec::with_capacity(nq * queries.first().map_or(0, |x| x.len()));
+        for x in queries {
+            q.extend_from_slice(x);
+        }
+        let (mut ids, mut d, mut len) = (vec![0u64; nq * k], vec![0f32; nq * k], vec![0u64; nq]);
+        check(unsafe {
+            sys::phnsw_search_batch_topk(self.ix, q.as_ptr(), std::ptr::null(), nq as u64, &psp, 0, std::ptr::null(), k as u64,
+                                         ids.as_mut_ptr(), d.as_mut_ptr(), len.as_mut_ptr())
+        });
+        (0..nq).map(|i| (0..len[i] as usize).map(|j| (VectorId(ids[i * k + j] as usize), d[i * k + j])).collect()).collect()
+    }
+
+    /// `Hnsw::search_instrumented(v, sp)`  lib.rs:667-673
+    pub fn search_instrumented(&self, v: AbstractVector<Vec<f32>>, sp: SearchParameters) -> (Vec<(VectorId, f32)>, usize) {
+        let ef = sp.number_of_candidates;
+        let psp = sp_c(sp);
+        let (mut ids, mut d, mut len, mut index) = (vec![0u64; ef], vec![0f32; ef], 0u64, 0u64);
+        let rc = match &v {
+            AbstractVector::Stored(i) => {
+                let q = i.0 as u64;
+                unsafe {
+                    sys::phnsw_search_instrumented(self.ix, std::ptr::null(), &q, 1, &psp, ids.as_mut_ptr(), d.as_mut_ptr(),
+                                                   &mut len, &mut index)
+                }
+            }
+            AbstractVector::Unstored(x) => unsafe {
+                sys::phnsw_search_instrumented(self.ix, x.as_ptr(), std::ptr::null(), 1, &psp, ids.as_mut_ptr(),
+                                               d.as_mut_ptr(), &mut len, &mut index)
+            },
+        };
+        check(rc);
+        ((0..len as usize).map(|j| (VectorId(ids[j] as usize), d[j])).collect(), index as usize) // u64::MAX == usize::MAX
     }
 
     /// `Hnsw::improve_index(bp, last_recall, progress)`  lib.rs:1664-1669

@@ -73,6 +73,78 @@ pub struct phnsw_index {
 pub type phnsw_progress_cb =
     Option<unsafe extern "C" fn(user: *mut c_void, phase: *const c_char, done: u64, total: u64) -> c_int>;
 
+// ---- sharded build (include/phnsw.h "sharded build"): the collective seam, its statistics, the phase engine
+
+/// all_gather(ctx, send, recv, bytes, stream): device pointers + a hipStream_t to enqueue on, or host pointers
+/// (host_buffers = 1, stream NULL, returns when recv is complete)
+pub type phnsw_all_gather_fn =
+    Option<unsafe extern "C" fn(ctx: *mut c_void, send: *const c_void, recv: *mut c_void, bytes: u64, stream: *mut c_void) -> c_int>;
+/// all_reduce_sum(ctx, values, count): element-wise sum of host u64 over the ranks, in place
+pub type phnsw_all_reduce_sum_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, values: *mut u64, count: u32) -> c_int>;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct phnsw_comm {
+    pub rank: u32,
+    pub world: u32,
+    pub host_buffers: u32,
+    pub emulate: u32,
+    pub ctx: *mut c_void,
+    pub all_gather: phnsw_all_gather_fn,
+    pub all_reduce_sum: phnsw_all_reduce_sum_fn,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct phnsw_sharded_stats {
+    pub seconds_total: f64,
+    pub seconds_sharded: f64,
+    pub seconds_replicated: f64,
+    pub seconds_comm: f64,
+    pub seconds_others: f64,
+    pub all_gather_bytes: u64,
+    pub all_gather_calls: u64,
+    pub all_reduce_calls: u64,
+    pub phases: u64,
+    pub phases_whole: u64,
+    pub seconds_by_phase: [f64; 10],
+}
+
+/// the phases behind the sharded driver as callbacks (tests plug the CPU oracle in; hosts normally never touch it)
+#[repr(C)]
+pub struct phnsw_shard_engine {
+    pub ctx: *mut c_void,
+    pub id_bytes: u32,
+    pub host_buffers: u32,
+    pub alloc: Option<unsafe extern "C" fn(ctx: *mut c_void, bytes: u64) -> *mut c_void>,
+    pub release: Option<unsafe extern "C" fn(ctx: *mut c_void, p: *mut c_void)>,
+    pub copy2d: Option<unsafe extern "C" fn(ctx: *mut c_void, dst: *mut c_void, dpitch: u64, src: *const c_void, spitch: u64,
+                                            width: u64, height: u64) -> c_int>,
+    pub plan: Option<unsafe extern "C" fn(ctx: *mut c_void, vids: *const u64, n: u64, shuffled: *mut u64, layer_sizes: *mut u64,
+                                          max_layers: u32, layer_count: *mut u32) -> c_int>,
+    pub layer_begin: Option<unsafe extern "C" fn(ctx: *mut c_void, vids: *const u64, n: u64, w: u64, needs_phases: *mut c_int,
+                                                 k: *mut u32) -> c_int>,
+    pub layer_init_search: Option<unsafe extern "C" fn(ctx: *mut c_void, first: u64, count: u64, ids: *mut c_void, d: *mut c_float,
+                                                       len: *mut c_void) -> c_int>,
+    pub layer_seed: Option<unsafe extern "C" fn(ctx: *mut c_void, init_ids: *const c_void, init_d: *const c_float,
+                                                init_len: *const c_void, first: u64, count: u64, rows: *mut c_void,
+                                                rows_d: *mut c_float) -> c_int>,
+    pub layer_finish: Option<unsafe extern "C" fn(ctx: *mut c_void, rows: *const c_void, rows_d: *const c_float) -> c_int>,
+    pub layer_count: Option<unsafe extern "C" fn(ctx: *mut c_void) -> u32>,
+    pub layer_nodes: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32) -> u64>,
+    pub link_search: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, sp: *const phnsw_search_params,
+                                                 link_count: u64, first: u64, count: u64, ids: *mut c_void, d: *mut c_float,
+                                                 len: *mut c_void) -> c_int>,
+    pub link_apply: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, link_count: u64, ids: *const c_void,
+                                                d: *const c_float, len: *const c_void, added: *mut u64) -> c_int>,
+    pub recall_hits: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, op: *const phnsw_optimization_params,
+                                                 first: u64, count: u64, hits: *mut u64, selection: *mut u64) -> c_int>,
+    pub discover_hits: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, sp: *const phnsw_search_params,
+                                                   first: u64, count: u64, hit: *mut c_void) -> c_int>,
+    pub promote_from_hits: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, hit: *const c_void,
+                                                       promoted: *mut c_int) -> c_int>,
+}
+
 extern "C" {
     pub fn phnsw_default_search_params(sp: *mut phnsw_search_params);
     pub fn phnsw_default_build_params(bp: *mut phnsw_build_params);
@@ -132,6 +204,12 @@ extern "C" {
                                      sp: *const phnsw_search_params, upto_layers: u32, exclude: *const u64,
                                      out_ids: *mut u64, out_d: *mut c_float, out_len: *mut u64,
                                      out_stats: *mut u64) -> c_int;
+    pub fn phnsw_search_batch_topk(ix: *const phnsw_index, queries: *const c_float, qids: *const u64, nq: u64,
+                                   sp: *const phnsw_search_params, upto_layers: u32, exclude: *const u64, k: u64,
+                                   out_ids: *mut u64, out_d: *mut c_float, out_len: *mut u64) -> c_int;
+    pub fn phnsw_search_instrumented(ix: *const phnsw_index, queries: *const c_float, qids: *const u64, nq: u64,
+                                     sp: *const phnsw_search_params, out_ids: *mut u64, out_d: *mut c_float,
+                                     out_len: *mut u64, out_index_distance: *mut u64) -> c_int;
     pub fn phnsw_search_batch_device(ix: *const phnsw_index, queries_dev: *const c_float, ldq: u32,
                                      qids_dev: *const u32, nq: u64, sp: *const phnsw_search_params,
                                      upto_layers: u32, exclude_dev: *const u32, out_ids_dev: *mut u32,
@@ -142,6 +220,7 @@ extern "C" {
     pub fn phnsw_last_search_dispatches(ix: *const phnsw_index, cap: u32, count: *mut u32, ms: *mut c_float,
                                         n_dist: *mut u64, n_hops: *mut u64, layer_lo: *mut u32,
                                         layer_hi: *mut u32) -> c_int;
+    pub fn phnsw_last_search_table_evals(ix: *const phnsw_index, cap: u32, count: *mut u32, n_table: *mut u64) -> c_int;
     pub fn phnsw_dense_top_layers(ix: *const phnsw_index, number_of_candidates: u64, layers: *mut u32, nodes: *mut u64,
                                   matrix_cores: *mut u32) -> c_int;
 
@@ -171,6 +250,22 @@ extern "C" {
     pub fn phnsw_recall_hits(ix: *mut phnsw_index, layer_from_top: u32, op: *const phnsw_optimization_params,
                              first: u64, count: u64, out_hits: *mut u64, out_selection: *mut u64) -> c_int;
 
+    // ---- sharded build (BASELINE config 4): one process per GPU, RCCL or a host-supplied transport
+    pub fn phnsw_build_sharded(s: *mut phnsw_store, vids: *const u64, n: u64, bp: *const phnsw_build_params,
+                               comm: *const phnsw_comm, cb: phnsw_progress_cb, user: *mut c_void,
+                               out: *mut *mut phnsw_index, stats: *mut phnsw_sharded_stats) -> c_int;
+    pub fn phnsw_improve_index_sharded(ix: *mut phnsw_index, bp: *const phnsw_build_params, last_recall: c_float,
+                                       comm: *const phnsw_comm, out_recall: *mut c_float,
+                                       stats: *mut phnsw_sharded_stats) -> c_int;
+    pub fn phnsw_sharded_tuning(shard_min: u64, subchunks: u32, sub_min: u64) -> c_int;
+    pub fn phnsw_comm_rccl_unique_id(out_id128: *mut u8) -> c_int;
+    pub fn phnsw_comm_rccl_create(id128: *const u8, rank: u32, world: u32, device: c_int, out: *mut *mut phnsw_comm) -> c_int;
+    pub fn phnsw_comm_destroy(c: *mut phnsw_comm);
+    pub fn phnsw_comm_selftest(comm: *const phnsw_comm, bytes: u64) -> c_int;
+    pub fn phnsw_build_sharded_engine(e: *const phnsw_shard_engine, vids: *const u64, n: u64,
+                                      bp: *const phnsw_build_params, comm: *const phnsw_comm,
+                                      stats: *mut phnsw_sharded_stats) -> c_int;
+
     // ---- product quantisation (pq.rs)
     pub fn phnsw_store_create_pq(full: *mut phnsw_store, m: u32, ksub: u32, seed: u64,
                                  out: *mut *mut phnsw_store) -> c_int;
@@ -180,6 +275,12 @@ extern "C" {
                                         centroid_bp: *const phnsw_build_params,
                                         quantized_search: *const phnsw_search_params, centroid_metric: c_int,
                                         out: *mut *mut phnsw_store) -> c_int;
+    pub fn phnsw_store_create_pq_sharded(full: *mut phnsw_store, m: u32, ksub: u32, seed: u64, kmeans_iters: u32,
+                                         sample: u64, comm: *const phnsw_comm, out: *mut *mut phnsw_store) -> c_int;
+    pub fn phnsw_store_create_pq_shared_sharded(full: *mut phnsw_store, dsub: u32, n_centroids: u32, seed: u64,
+                                                centroid_bp: *const phnsw_build_params,
+                                                quantized_search: *const phnsw_search_params, centroid_metric: c_int,
+                                                comm: *const phnsw_comm, out: *mut *mut phnsw_store) -> c_int;
     pub fn phnsw_pq_shared_read(s: *const phnsw_store, codes: *mut u16, codebook: *mut c_float) -> c_int;
     pub fn phnsw_pq_shared_reconstruct_store(s: *const phnsw_store, out: *mut *mut phnsw_store) -> c_int;
     pub fn phnsw_pq_info(s: *const phnsw_store, m: *mut u32, ksub: *mut u32, dsub: *mut u32) -> c_int;
