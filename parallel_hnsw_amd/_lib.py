@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphnsw.so")
+LIB_PATH = os.environ.get("PHNSW_LIB_PATH") or os.path.join(_HERE, "libphnsw.so")  # the override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 
