@@ -248,6 +248,14 @@ int phnsw_build_plan(const uint64_t *vids, uint64_t n, const phnsw_build_params 
  * first layer of a stack) -> init_search(range) -> seed(range) -> finish */
 int phnsw_layer_begin(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
                       const phnsw_build_params *bp, int *needs_phases);
+/* the same for a sharded driver: the cells of the new layer's locality schedule (a GEMM of its vectors against the
+ * store's anchors -- a scheduling hint, never part of a result, but the one costly step of begin) are left out when
+ * *needs_cells comes back 1: every rank computes a node range (cells_device), the ranges are all-gathered, every
+ * rank installs the whole array (set_cells_device) */
+int phnsw_layer_begin_sharded(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
+                              const phnsw_build_params *bp, int *needs_phases, int *needs_cells);
+int phnsw_layer_cells_device(phnsw_index *ix, uint64_t first, uint64_t count, uint32_t *out_pos);
+int phnsw_layer_set_cells_device(phnsw_index *ix, const uint32_t *pos);
 /* out_* : [count][K] NodeIds of the new layer / distances, [count] lengths;
  * K = initial_partition_search.number_of_candidates  (search.rs:32-71) */
 int phnsw_layer_init_search_device(phnsw_index *ix, const phnsw_build_params *bp, uint64_t first,
@@ -335,7 +343,7 @@ int phnsw_build_sharded(phnsw_store *s, const uint64_t *vids, uint64_t n, const 
 int phnsw_improve_index_sharded(phnsw_index *ix, const phnsw_build_params *bp, float last_recall,
                                 const phnsw_comm *comm, float *out_recall, phnsw_sharded_stats *stats);
 /* work lists shorter than shard_min run whole on every rank (default 4096); a rank's share is cut into
- * `subchunks` pieces of at least sub_min items whose all-gathers overlap the next piece (defaults 4, 8192).
+ * `subchunks` pieces of at least sub_min items whose all-gathers overlap the next piece (defaults 4, 65536).
  * 0 keeps a value.  Process-wide; for tests and tuning. */
 int phnsw_sharded_tuning(uint64_t shard_min, uint32_t subchunks, uint64_t sub_min);
 
@@ -380,6 +388,10 @@ typedef struct phnsw_shard_engine {
   int (*discover_hits)(void *ctx, uint32_t layer_from_top, const phnsw_search_params *sp, uint64_t first,
                        uint64_t count, void *hit);
   int (*promote_from_hits)(void *ctx, uint32_t layer_from_top, const void *hit, int *promoted);
+  /* optional (NULL: layer_begin does it all): when layer_begin sets *needs_phases to 3 instead of 1 the driver
+   * shards layer_cells (u32 per node) like any phase and hands the whole array to layer_set_cells */
+  int (*layer_cells)(void *ctx, uint64_t first, uint64_t count, void *pos);
+  int (*layer_set_cells)(void *ctx, const void *pos);
 } phnsw_shard_engine;
 int phnsw_build_sharded_engine(const phnsw_shard_engine *e, const uint64_t *vids, uint64_t n,
                                const phnsw_build_params *bp, const phnsw_comm *comm, phnsw_sharded_stats *stats);

@@ -141,6 +141,14 @@ class Hnsw {
     check(phnsw_build(c.handle(), vs.data(), vs.size(), &bp, nullptr, nullptr, &ix));
     return Hnsw(ix, &c, bp);
   }
+  // Hnsw::generate with every per-node phase split over the ranks of `comm` (BASELINE config 4: one process per
+  // GPU; phnsw_comm_rccl_create for the built-in RCCL transport, or two callbacks of the host's own)
+  static Hnsw generate_sharded(const Comparator &c, const std::vector<VectorId> &vs, const BuildParameters &bp,
+                               const phnsw_comm &comm, phnsw_sharded_stats *stats = nullptr) {
+    phnsw_index *ix = nullptr;
+    check(phnsw_build_sharded(c.handle(), vs.data(), vs.size(), &bp, &comm, nullptr, nullptr, &ix, stats));
+    return Hnsw(ix, &c, bp);
+  }
   // adopt layers built elsewhere (top first), e.g. deserialised by the crate
   static Hnsw from_layers(const Comparator &c, const std::vector<Layer> &layers) {
     std::vector<uint64_t> counts, widths;
@@ -198,6 +206,32 @@ class Hnsw {
     for (uint64_t i = 0; i < nq; i++)
       for (uint64_t j = 0; j < len[i]; j++) out[i].push_back({ids[i * ef + j], d[i * ef + j]});
     return out;
+  }
+  // raw queries, the best k results of each: the truncation of lib.rs:1118 done before the transfer
+  std::vector<SearchResult> search_many_topk(const std::vector<const float *> &queries, const SearchParameters &sp,
+                                             uint64_t k) const {
+    const uint64_t nq = queries.size(), dim = c_->dim();
+    std::vector<float> q(nq * dim);
+    for (uint64_t i = 0; i < nq; i++) std::copy(queries[i], queries[i] + dim, q.begin() + i * dim);
+    std::vector<uint64_t> ids(nq * k), len(nq);
+    std::vector<float> d(nq * k);
+    check(phnsw_search_batch_topk(ix_, q.data(), nullptr, nq, &sp, 0, nullptr, k, ids.data(), d.data(), len.data()));
+    std::vector<SearchResult> out(nq);
+    for (uint64_t i = 0; i < nq; i++)
+      for (uint64_t j = 0; j < len[i]; j++) out[i].push_back({ids[i * k + j], d[i * k + j]});
+    return out;
+  }
+  // Hnsw::search_instrumented(v, sp) -> (results, index_distance)  lib.rs:667-673
+  std::pair<SearchResult, uint64_t> search_instrumented(const AbstractVector &v, const SearchParameters &sp) const {
+    const uint64_t ef = sp.number_of_candidates;
+    std::vector<uint64_t> ids(ef);
+    std::vector<float> d(ef);
+    uint64_t len = 0, index = 0;
+    check(phnsw_search_instrumented(ix_, v.stored ? nullptr : v.vec, v.stored ? &v.id : nullptr, 1, &sp, ids.data(), d.data(),
+                                    &len, &index));
+    SearchResult r;
+    for (uint64_t j = 0; j < len; j++) r.push_back({ids[j], d[j]});
+    return {r, index};
   }
   // improve_index(bp, last_recall: Option<f32>, progress)  lib.rs:1664-1686; NaN = None
   float improve_index(const BuildParameters &bp, float last_recall = __builtin_nanf("")) {

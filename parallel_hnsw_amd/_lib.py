@@ -86,6 +86,8 @@ class ShardEngine(C.Structure):
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))),
         ("discover_hits", C.CFUNCTYPE(C.c_int, _vpx, _u32x, C.POINTER(SearchParams), _u64x, _u64x, _vpx)),
         ("promote_from_hits", C.CFUNCTYPE(C.c_int, _vpx, _u32x, _vpx, C.POINTER(C.c_int))),
+        ("layer_cells", C.CFUNCTYPE(C.c_int, _vpx, _u64x, _u64x, _vpx)),
+        ("layer_set_cells", C.CFUNCTYPE(C.c_int, _vpx, _vpx)),
     ]
 
 # name -> (restype, argtypes): every symbol include/phnsw.h declares
@@ -133,6 +135,9 @@ SYMBOLS = {
     "phnsw_index_create": (_i32, [_vp, C.POINTER(BuildParams), _pp]),
     "phnsw_build_plan": (_i32, [_vp, _u64, C.POINTER(BuildParams), _vp, _vp, _u32, C.POINTER(_u32)]),
     "phnsw_layer_begin": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams), C.POINTER(_i32)]),
+    "phnsw_layer_begin_sharded": (_i32, [_vp, _vp, _u64, _u64, C.POINTER(BuildParams), C.POINTER(_i32), C.POINTER(_i32)]),
+    "phnsw_layer_cells_device": (_i32, [_vp, _u64, _u64, _vp]),
+    "phnsw_layer_set_cells_device": (_i32, [_vp, _vp]),
     "phnsw_layer_init_search_device": (_i32, [_vp, C.POINTER(BuildParams), _u64, _u64, _vp, _vp, _vp]),
     "phnsw_layer_seed_device": (_i32, [_vp, C.POINTER(BuildParams), _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "phnsw_layer_finish_device": (_i32, [_vp, _vp, _vp]),

@@ -367,27 +367,30 @@ void ph_store_anchors_free(phnsw_store *s) {
   s->anchor_rank = nullptr;
 }
 
-// L.pos[node] = chain rank of the node's nearest anchor.  No-op for small layers, PQ stores and
-// the L2 metric (the GEMM scores dot products).
-int ph_layer_anchor_pos(const phnsw_store *cs, PhLayerHost &L) {
+// whether a layer carries cells at all: not the small ones, not PQ stores, not the L2 metric (the GEMM scores dot
+// products)
+bool ph_layer_wants_cells(const phnsw_store *s, uint32_t n_nodes) {
+  return n_nodes >= PH_POS_MIN && s->rows && s->n >= 65536 && s->metric != PHNSW_METRIC_L2 && !getenv("PHNSW_NO_LOCALITY");
+}
+
+// out_pos[i] = chain rank of the nearest anchor of node first + i, for count nodes of the layer (the sharded build
+// gives every rank a node range and all-gathers the ranks' pieces: the GEMM is the one step of layer_begin that costs)
+int ph_layer_cells_range(const phnsw_store *cs, const PhLayerHost &L, uint32_t first, uint32_t count, uint32_t *out_pos) {
   phnsw_store *s = const_cast<phnsw_store *>(cs);
-  const uint32_t n = L.n_nodes;
-  if (L.pos || n < PH_POS_MIN || !s->rows || s->n < 65536 || s->metric == PHNSW_METRIC_L2 || getenv("PHNSW_NO_LOCALITY"))
-    return 0;
+  if (count == 0) return 0;
   int rc = ph_store_anchors(s);
   if (rc) return rc;
   const uint32_t A = s->n_anchors, ld = s->ld;
   const uint32_t QC = 65536;  // layer vectors per GEMM pass
   float *qrows = nullptr, *scores = nullptr;
-  hipError_t e = hipMalloc(&scores, (size_t)std::min(QC, n) * A * 4);
-  if (e == hipSuccess && !L.identity) e = hipMalloc(&qrows, (size_t)std::min(QC, n) * ld * 4);
-  if (e == hipSuccess) e = hipMalloc(&L.pos, (size_t)n * 4);
+  hipError_t e = hipMalloc(&scores, (size_t)std::min(QC, count) * A * 4);
+  if (e == hipSuccess && !L.identity) e = hipMalloc(&qrows, (size_t)std::min(QC, count) * ld * 4);
   if (e == hipSuccess) {
-    for (uint32_t first = 0; first < n; first += QC) {
-      const uint32_t cnt = std::min(QC, n - first);
-      const float *Q = s->rows + (uint64_t)first * ld;  // identity layer: node i is row i
+    for (uint32_t at = 0; at < count; at += QC) {
+      const uint32_t cnt = std::min(QC, count - at);
+      const float *Q = s->rows + (uint64_t)(first + at) * ld;  // identity layer: node i is row i
       if (!L.identity) {
-        hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((cnt + 3) / 4), dim3(256), 0, 0, s->rows, ld, L.nodes + first,
+        hipLaunchKernelGGL(ph_gather_rows_f32_kernel, dim3((cnt + 3) / 4), dim3(256), 0, 0, s->rows, ld, L.nodes + first + at,
                            1u, cnt, qrows);
         Q = qrows;
       }
@@ -396,19 +399,30 @@ int ph_layer_anchor_pos(const phnsw_store *cs, PhLayerHost &L) {
       hipLaunchKernelGGL(ph_gemm_nt_mfma_kernel, grid, dim3(256), 0, 0, Q, ld, cnt, s->anchors, ld, A,
                          std::min<uint32_t>(ld, 256u), scores, (uint64_t)A);
       hipLaunchKernelGGL(ph_argmax_rows_kernel, dim3(std::min<uint32_t>(cnt, 256u * 16u)), dim3(64), 0, 0, scores,
-                         (uint64_t)A, A, cnt, L.pos + first);
+                         (uint64_t)A, A, cnt, out_pos + at);
     }
-    hipLaunchKernelGGL(ph_rank_of_cell_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, L.pos, n, s->anchor_rank);
+    hipLaunchKernelGGL(ph_rank_of_cell_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, out_pos, count, s->anchor_rank);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
-  if (e != hipSuccess) {
-    rc = ph_hip_fail(e, "layer cells (anchor GEMM)", __FILE__, __LINE__);
-    if (L.pos) hipFree(L.pos);
-    L.pos = nullptr;
-  }
+  if (e != hipSuccess) rc = ph_hip_fail(e, "layer cells (anchor GEMM)", __FILE__, __LINE__);
   if (qrows) hipFree(qrows);
   if (scores) hipFree(scores);
+  return rc;
+}
+
+// L.pos[node] = chain rank of the node's nearest anchor, for the whole layer.  No-op when the layer has its
+// cells or wants none.
+int ph_layer_anchor_pos(const phnsw_store *cs, PhLayerHost &L) {
+  const uint32_t n = L.n_nodes;
+  if (L.pos || !ph_layer_wants_cells(cs, n)) return 0;
+  hipError_t e = hipMalloc(&L.pos, (size_t)n * 4);
+  if (e != hipSuccess) return ph_hip_fail(e, "layer cells", __FILE__, __LINE__);
+  int rc = ph_layer_cells_range(cs, L, 0, n, L.pos);
+  if (rc) {
+    hipFree(L.pos);
+    L.pos = nullptr;
+  }
   return rc;
 }
 

@@ -730,7 +730,7 @@ static int symmetric_store(const phnsw_store *s) {
 }
 
 static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64, uint64_t W64,
-                            const phnsw_build_params *bp, int *needs_phases) {
+                            const phnsw_build_params *bp, int *needs_phases, int *defer_cells = nullptr) {
   const phnsw_store *s = ix->store;
   PH_TRY(symmetric_store(s));
   if (!vids || n64 == 0 || W64 == 0 || W64 > 64 || n64 >= 0x7FFFFFFFull || !bp) {
@@ -788,9 +788,14 @@ static int layer_begin_impl(phnsw_index *ix, const uint64_t *vids, uint64_t n64,
     delete P;
     return rc;
   }
+  if (defer_cells) *defer_cells = 0;
   if (!rc) {
     PhTimer ta("  layer cells (anchor GEMM)", n);
-    rc = ph_layer_anchor_pos(ix->store, P->L);  // locality schedule of the build rounds (bruteforce.hip)
+    // locality schedule of the build rounds (bruteforce.hip); a sharded driver computes it range by range instead
+    if (defer_cells && !ix->layers.empty() && ph_layer_wants_cells(ix->store, n))
+      *defer_cells = 1;
+    else
+      rc = ph_layer_anchor_pos(ix->store, P->L);
   }
   if (rc) {
     ph_layer_free(P->L);
@@ -1566,6 +1571,34 @@ extern "C" int phnsw_layer_begin(phnsw_index *ix, const uint64_t *vids, uint64_t
   PH_TRY(enter(ix));
   if (!needs_phases) return PHNSW_E_INVALID;
   return layer_begin_impl(ix, vids, n, neighborhood_size, bp, needs_phases);
+} catch (...) { return ph_caught(); }
+// the sharded form of layer_begin: the cells of the new layer (the anchor GEMM, the one costly step) are left to
+// phnsw_layer_cells_device (a node range per rank) + phnsw_layer_set_cells_device (the all-gathered array)
+extern "C" int phnsw_layer_begin_sharded(phnsw_index *ix, const uint64_t *vids, uint64_t n, uint64_t neighborhood_size,
+                                         const phnsw_build_params *bp, int *needs_phases, int *needs_cells) try {
+  PH_TRY(enter(ix));
+  if (!needs_phases || !needs_cells) return PHNSW_E_INVALID;
+  return layer_begin_impl(ix, vids, n, neighborhood_size, bp, needs_phases, needs_cells);
+} catch (...) { return ph_caught(); }
+extern "C" int phnsw_layer_cells_device(phnsw_index *ix, uint64_t first, uint64_t count, uint32_t *out_pos) try {
+  PH_TRY(enter(ix));
+  PhPendingLayer *P = ix->pending;
+  if (!P || !out_pos || first + count > P->L.n_nodes) {
+    ph_set_error("layer_cells: no pending layer or range out of bounds");
+    return PHNSW_E_INVALID;
+  }
+  return ph_layer_cells_range(ix->store, P->L, (uint32_t)first, (uint32_t)count, out_pos);
+} catch (...) { return ph_caught(); }
+extern "C" int phnsw_layer_set_cells_device(phnsw_index *ix, const uint32_t *pos) try {
+  PH_TRY(enter(ix));
+  PhPendingLayer *P = ix->pending;
+  if (!P || !pos) {
+    ph_set_error("layer_set_cells: no pending layer");
+    return PHNSW_E_INVALID;
+  }
+  if (!P->L.pos) PH_HIP(hipMalloc(&P->L.pos, (size_t)P->L.n_nodes * 4));
+  PH_HIP(hipMemcpy(P->L.pos, pos, (size_t)P->L.n_nodes * 4, hipMemcpyDeviceToDevice));
+  return 0;
 } catch (...) { return ph_caught(); }
 extern "C" int phnsw_layer_init_search_device(phnsw_index *ix, const phnsw_build_params *bp, uint64_t first,
                                               uint64_t count, uint32_t *out_ids, float *out_d, uint32_t *out_len) try {

@@ -256,6 +256,8 @@ static inline bool ph_layer_own_launch(uint64_t n_nodes, uint32_t ld) {
   return n_nodes * (uint64_t)ld * 4u > limit;
 }
 int ph_layer_anchor_pos(const phnsw_store *s, PhLayerHost &L);  // bruteforce.hip
+bool ph_layer_wants_cells(const phnsw_store *s, uint32_t n_nodes);
+int ph_layer_cells_range(const phnsw_store *s, const PhLayerHost &L, uint32_t first, uint32_t count, uint32_t *out_pos);
 void ph_store_anchors_free(phnsw_store *s);
 int ph_order_by_keys_device(const uint32_t *keys, uint32_t n, uint32_t *order_out, hipStream_t st);
 int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const uint32_t **out);

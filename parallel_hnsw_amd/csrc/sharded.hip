@@ -50,7 +50,10 @@ namespace {
 uint64_t g_shard_min = 4096;  // shorter work lists run whole on every rank: a launch over a few thousand queries
                               // takes one query latency however few of them a rank keeps
 uint32_t g_subchunks = 4;
-uint64_t g_sub_min = 8192;
+// A piece is a launch of its own, and a launch costs ~1.6 ms beyond its queries (ramp-up and tail of the persistent
+// grid, probe_tail.py): pieces pay off only where the transfer they hide is longer than that -- shares of a quarter
+// of a million nodes and more (a layer of 2M nodes at 8 ranks).  At 1M x 768 the whole build gathers 1.5 GB per rank.
+uint64_t g_sub_min = 65536;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -294,6 +297,12 @@ struct Driver {
     PH_TRY(replicated(6, [&] { return e->layer_begin(e->ctx, vids, n, W, &needs, &K); }));
     if (!needs) return 0;
     const uint32_t ib = e->id_bytes;
+    if ((needs & 2) && e->layer_cells && e->layer_set_cells) {  // the cells of the locality schedule, range by range
+      std::vector<void *> pos;
+      PH_TRY(phase(6, n, {{1, 4}}, [&](uint64_t f, uint64_t c, void *const *o) { return e->layer_cells(e->ctx, f, c, o[0]); }, pos));
+      PH_TRY(replicated(6, [&] { return e->layer_set_cells(e->ctx, pos[0]); }));
+      release(pos[0]);
+    }
     std::vector<void *> init, rows;
     PH_TRY(phase(0, n, {{K, ib}, {K, 4}, {1, ib}},
                  [&](uint64_t f, uint64_t c, void *const *o) {
@@ -533,8 +542,15 @@ int gpu_plan(void *c, const uint64_t *vids, uint64_t n, uint64_t *sh, uint64_t *
 int gpu_layer_begin(void *c, const uint64_t *vids, uint64_t n, uint64_t W, int *needs, uint32_t *K) {
   GpuCtx *g = (GpuCtx *)c;
   *K = (uint32_t)g->bp.initial_partition_search.number_of_candidates;
-  return phnsw_layer_begin(g->ix, vids, n, W, &g->bp, needs);
+  int cells = 0;
+  int rc = phnsw_layer_begin_sharded(g->ix, vids, n, W, &g->bp, needs, &cells);
+  if (!rc && *needs && cells) *needs |= 2;
+  return rc;
 }
+int gpu_layer_cells(void *c, uint64_t first, uint64_t count, void *pos) {
+  return phnsw_layer_cells_device(((GpuCtx *)c)->ix, first, count, (uint32_t *)pos);
+}
+int gpu_layer_set_cells(void *c, const void *pos) { return phnsw_layer_set_cells_device(((GpuCtx *)c)->ix, (const uint32_t *)pos); }
 int gpu_layer_init_search(void *c, uint64_t first, uint64_t count, void *ids, float *d, void *len) {
   GpuCtx *g = (GpuCtx *)c;
   return phnsw_layer_init_search_device(g->ix, &g->bp, first, count, (uint32_t *)ids, d, (uint32_t *)len);
@@ -594,6 +610,8 @@ phnsw_shard_engine gpu_engine(GpuCtx *g) {
   e.recall_hits = gpu_recall_hits;
   e.discover_hits = gpu_discover_hits;
   e.promote_from_hits = gpu_promote_from_hits;
+  e.layer_cells = gpu_layer_cells;
+  e.layer_set_cells = gpu_layer_set_cells;
   return e;
 }
 

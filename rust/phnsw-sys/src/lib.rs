@@ -143,6 +143,8 @@ pub struct phnsw_shard_engine {
                                                    first: u64, count: u64, hit: *mut c_void) -> c_int>,
     pub promote_from_hits: Option<unsafe extern "C" fn(ctx: *mut c_void, layer_from_top: u32, hit: *const c_void,
                                                        promoted: *mut c_int) -> c_int>,
+    pub layer_cells: Option<unsafe extern "C" fn(ctx: *mut c_void, first: u64, count: u64, pos: *mut c_void) -> c_int>,
+    pub layer_set_cells: Option<unsafe extern "C" fn(ctx: *mut c_void, pos: *const c_void) -> c_int>,
 }
 
 extern "C" {
@@ -230,6 +232,11 @@ extern "C" {
                             layer_sizes: *mut u64, max_layers: u32, layer_count: *mut u32) -> c_int;
     pub fn phnsw_layer_begin(ix: *mut phnsw_index, vids: *const u64, n: u64, neighborhood_size: u64,
                              bp: *const phnsw_build_params, needs_phases: *mut c_int) -> c_int;
+    pub fn phnsw_layer_begin_sharded(ix: *mut phnsw_index, vids: *const u64, n: u64, neighborhood_size: u64,
+                                     bp: *const phnsw_build_params, needs_phases: *mut c_int,
+                                     needs_cells: *mut c_int) -> c_int;
+    pub fn phnsw_layer_cells_device(ix: *mut phnsw_index, first: u64, count: u64, out_pos: *mut u32) -> c_int;
+    pub fn phnsw_layer_set_cells_device(ix: *mut phnsw_index, pos: *const u32) -> c_int;
     pub fn phnsw_layer_init_search_device(ix: *mut phnsw_index, bp: *const phnsw_build_params, first: u64,
                                           count: u64, out_ids: *mut u32, out_d: *mut c_float,
                                           out_len: *mut u32) -> c_int;

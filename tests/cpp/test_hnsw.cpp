@@ -105,6 +105,28 @@ static void test_generate_and_improve(const Comparator &c) {  // lib.rs:1994-201
     EXPECT(!results.empty() && results[0].first == i);  // test_small_index_improvement  lib.rs:2280-2283
   }
   EXPECT(hnsw.entry_vector() == hnsw.get_layer_from_top(0).nodes[0]);
+  {  // search_instrumented (lib.rs:667-673) returns search's results; top-k == the leading k of them
+    auto sp = hnsw.build_parameters.optimization.search;
+    auto plain = hnsw.search(AbstractVector::Unstored(data.data()), sp);
+    auto inst = hnsw.search_instrumented(AbstractVector::Unstored(data.data()), sp);
+    EXPECT(inst.first == plain);
+    auto stored = hnsw.search_instrumented(AbstractVector::Stored(3), sp);
+    EXPECT(!stored.first.empty() && stored.first[0].first == 3);
+    auto top = hnsw.search_many_topk({data.data(), data.data() + 3}, sp, 2);
+    EXPECT(top.size() == 2 && top[0].size() == 2 && top[0][0] == plain[0] && top[0][1] == plain[1]);
+    // the sharded build through the C ABI with one process playing two ranks: the graph phnsw_build gives
+    phnsw_comm comm = {};
+    comm.rank = 0;
+    comm.world = 2;
+    comm.emulate = 1;
+    phnsw_sharded_tuning(1, 1, 1);
+    phnsw_sharded_stats st;
+    Hnsw sh = Hnsw::generate_sharded(c, vs, simple_bp(), comm, &st);
+    phnsw_sharded_tuning(4096, 4, 65536);
+    Hnsw ref = Hnsw::generate(c, vs, simple_bp());
+    EXPECT(sh.layer_count() == ref.layer_count() && st.all_gather_calls > 0);
+    EXPECT(sh.get_layer(0).neighbors == ref.get_layer(0).neighbors);
+  }
   // panics of the reference surface as exceptions
   bool threw = false;
   try {

@@ -204,7 +204,7 @@ def test_sharded_build_emulated_worlds_equal_phnsw_build():
             else:
                 assert st["all_gather_calls"] == 0  # nothing at this size is long enough to split
     finally:
-        sharded_tuning(4096, 4, 8192)
+        sharded_tuning(4096, 4, 65536)
 
 
 def test_rccl_transport_selftest_single_rank():

@@ -174,7 +174,7 @@ def _emulated_build(case, world, rank=0, subchunks=None, sub_min=None):
     try:
         b.generate(np.arange(case["n"], dtype=np.uint64))
     finally:
-        sharded_tuning(4096, 4, 8192)
+        sharded_tuning(4096, 4, 65536)
     return eng, b.stats
 
 
