@@ -356,6 +356,9 @@ void phnsw_comm_destroy(phnsw_comm *c);
 /* checks a communicator end to end before a build is trusted to it: every rank contributes a known pattern of
  * `bytes` bytes, verifies all world blocks of the all-gather, then the all-reduce.  Collective: every rank calls it. */
 int phnsw_comm_selftest(const phnsw_comm *comm, uint64_t bytes);
+/* what a collective costs: `iters` all-gathers of `bytes` per rank back to back -- *host_us = host time per call to
+ * enqueue it, *total_us = wall time per call until the last has landed.  Collective; device-buffer transports. */
+int phnsw_comm_benchmark(const phnsw_comm *comm, uint64_t bytes, uint32_t iters, double *host_us, double *total_us);
 
 /* The phase engine behind the sharded driver.  phnsw_build_sharded runs the driver over libphnsw's own
  * GPU phases (the phase API above); this entry runs the SAME driver over an engine given as callbacks,

@@ -156,6 +156,7 @@ SYMBOLS = {
     "phnsw_comm_rccl_create": (_i32, [_vp, _u32, _u32, _i32, C.POINTER(C.POINTER(Comm))]),
     "phnsw_comm_destroy": (None, [C.POINTER(Comm)]),
     "phnsw_comm_selftest": (_i32, [C.POINTER(Comm), _u64]),
+    "phnsw_comm_benchmark": (_i32, [C.POINTER(Comm), _u64, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "phnsw_build_sharded_engine": (_i32, [C.POINTER(ShardEngine), _vp, _u64, C.POINTER(BuildParams), C.POINTER(Comm),
                                           C.POINTER(ShardedStats)]),
     "phnsw_store_create_pq": (_i32, [_vp, _u32, _u32, _u64, _pp]),

@@ -932,6 +932,45 @@ extern "C" int phnsw_comm_selftest(const phnsw_comm *comm, uint64_t bytes) try {
   return 0;
 } catch (...) { return ph_caught(); }
 
+// What a collective costs the host and the wire: `iters` all-gathers of `bytes` per rank back to back on the
+// collectives' stream -- *host_us = host time per call to ENQUEUE it (what the build's critical path pays even when
+// the transfer hides behind the next piece's searches), *total_us = wall time per call until the last has landed.
+// Collective: every rank calls it.  Device-buffer transports only.
+extern "C" int phnsw_comm_benchmark(const phnsw_comm *comm, uint64_t bytes, uint32_t iters, double *host_us, double *total_us) try {
+  if (!comm || !comm->all_gather || comm->host_buffers || !bytes || !iters || !host_us || !total_us) {
+    ph_set_error("phnsw_comm_benchmark: needs a device-buffer communicator, bytes > 0, iters > 0");
+    return PHNSW_E_INVALID;
+  }
+  void *ds = nullptr, *dr = nullptr;
+  hipStream_t st = nullptr;
+  PH_HIP(hipMalloc(&ds, bytes));
+  hipError_t he = hipMalloc(&dr, bytes * comm->world);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipMemset(ds, 1, bytes);
+  int rc = 0;
+  double host = 0.0, t0 = 0.0;
+  for (uint32_t i = 0; he == hipSuccess && !rc && i < iters + 2; i++) {
+    if (i == 2) {  // two warm-up calls
+      he = hipStreamSynchronize(st);
+      t0 = now_s();
+      host = 0.0;
+    }
+    const double a = now_s();
+    rc = comm->all_gather(comm->ctx, ds, dr, bytes, st);
+    host += now_s() - a;
+  }
+  if (he == hipSuccess && !rc) he = hipStreamSynchronize(st);
+  const double total = now_s() - t0;
+  hipFree(ds);
+  if (dr) hipFree(dr);
+  if (st) hipStreamDestroy(st);
+  if (he != hipSuccess) return ph_hip_fail(he, "phnsw_comm_benchmark", __FILE__, __LINE__);
+  if (rc) return rc < 0 ? rc : PHNSW_E_INVALID;
+  *host_us = host / iters * 1e6;
+  *total_us = total / iters * 1e6;
+  return 0;
+} catch (...) { return ph_caught(); }
+
 extern "C" void phnsw_comm_destroy(phnsw_comm *pc) {
   if (!pc) return;
   if (pc->all_gather == rccl_all_gather && pc->ctx) {

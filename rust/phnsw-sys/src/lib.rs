@@ -269,6 +269,8 @@ extern "C" {
     pub fn phnsw_comm_rccl_create(id128: *const u8, rank: u32, world: u32, device: c_int, out: *mut *mut phnsw_comm) -> c_int;
     pub fn phnsw_comm_destroy(c: *mut phnsw_comm);
     pub fn phnsw_comm_selftest(comm: *const phnsw_comm, bytes: u64) -> c_int;
+    pub fn phnsw_comm_benchmark(comm: *const phnsw_comm, bytes: u64, iters: u32, host_us: *mut f64,
+                                total_us: *mut f64) -> c_int;
     pub fn phnsw_build_sharded_engine(e: *const phnsw_shard_engine, vids: *const u64, n: u64,
                                       bp: *const phnsw_build_params, comm: *const phnsw_comm,
                                       stats: *mut phnsw_sharded_stats) -> c_int;

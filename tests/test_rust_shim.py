@@ -12,9 +12,9 @@ SYS = os.path.join(ROOT, "rust", "phnsw-sys", "src", "lib.rs")
 WRAP = os.path.join(ROOT, "rust", "parallel-hnsw-gpu", "src", "lib.rs")
 
 C_SCALAR = {"int": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "uint16_t": "u16", "float": "f32", "char": "char",
-            "void": "void", "size_t": "usize"}
+            "void": "void", "size_t": "usize", "double": "f64"}
 R_SCALAR = {"c_int": "i32", "u32": "u32", "u64": "u64", "u8": "u8", "u16": "u16", "c_float": "f32", "f32": "f32", "c_char": "char",
-            "c_void": "void", "usize": "usize"}
+            "c_void": "void", "usize": "usize", "f64": "f64", "c_double": "f64"}
 
 
 def strip_c_comments(s):
