@@ -822,7 +822,38 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
                             "algorithmic_definition": "evaluations x m code bytes + hops x W x 4 B + re-ranked rows x row bytes"},
                "vs_f32_note": "PQ trades 32x less vector memory (96 B instead of 3 072 B per vector) for ~1.4x the hops at equal "
                               "recall; on this part a wave streams a 3 KB row faster than 96 dependent table look-ups issue"}
-        del qh, pids, pd_
+        del qh
+        # the reference's own flow beside it (pq.rs:336-338: the Hnsw is generated OVER the quantised vectors): the graph
+        # is built over the code rows with symmetric reconstruct-both distances, searched the same way
+        try:
+            t0 = time.time()
+            qr = ph.QuantizedHnsw(256, store, ph.BuildParameters(promote=0), m=m_)
+            torch.cuda.synchronize()
+            ref_build = time.time() - t0
+            qr.store.set_table_mode("u8")
+            rcells = []
+            for ef, pdp in [(256, 8), (512, 8), (1024, 16)]:
+                spq = ph.SearchParameters(ef, ef, pdp)
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    qr.search_batch_device(nq, spq, qstore.rows_dev, qstore.ld, pids.data_ptr(), pd_.data_ptr(),
+                                           pln.data_ptr(), pstatus.data_ptr(), pst.data_ptr(), stream=stream)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                rec = recall_at_10(pids.view(-1)[: nq * ef].view(nq, ef), gt)
+                rcells.append({"ef": ef, "probe_depth": pdp, "recall_at_10": round(rec, 4), "queries_per_s": round(nq / dt)})
+                log("  pq reference flow ef=%d pd=%d recall@10=%.4f %.0f q/s" % (ef, pdp, rec, nq / dt))
+            out["reference_flow"] = {"what": "QuantizedHnsw::new as the crate does it (pq.rs:326-338): Hnsw::generate over the code rows "
+                                             "(promotion off, DESIGN 9), then the same quantised search + f32 re-rank",
+                                     "build_s": round(ref_build, 1), "cells": rcells,
+                                     "note": "dot-product 'distances' between reconstructions are not a metric and make hubs: this "
+                                             "graph tops out below the 0.95 the adopted full-precision graph reaches, which is why "
+                                             "the headline PQ number uses the adopted graph"}
+            del qr
+        except Exception as exc:
+            out["reference_flow"] = {"error": repr(exc)}
+        del pids, pd_
         return out
     except Exception as exc:
         log("pq measurement failed: %r" % (exc,))
