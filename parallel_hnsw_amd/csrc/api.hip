@@ -399,6 +399,7 @@ int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const u
 // Layer::get_node's binary search (src/lib.rs:129-131)
 int ph_layer_upload(phnsw_index *ix, const uint32_t *nodes, const uint32_t *neighbors, uint32_t n, uint32_t W,
                     PhLayerHost *out) {
+  if (ix) ix->nodes_epoch++;  // a node list comes into being: tables keyed by node lists are void (tiny.hip)
   PhLayerHost l;
   l.n_nodes = n;
   l.W = W;
@@ -541,6 +542,7 @@ extern "C" void phnsw_index_destroy(phnsw_index *ix) {
   ph_workspace_free(ix->ws[0]);
   ph_workspace_free(ix->ws[1]);
   ph_host_stages_free(ix);
+  ph_build_table_free(ix);
   if (ix->totals) hipFree(ix->totals);
   phnsw_store_destroy(ix->store);
   delete ix;
@@ -634,7 +636,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride,
                      uint32_t *out_hit, float threshold, uint32_t first_node, float hit_eps, const uint32_t *order,
-                     uint32_t *out_index) {
+                     uint32_t *out_index, const PhRowHint *hint) {
   phnsw_index *mix = const_cast<phnsw_index *>(ix);
   PhSearchArgs a;
   fill_args(ix, sp, upto, a);
@@ -732,7 +734,13 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   if (rc) return rc;
   // The dense top layers (tiny.hip) keep one table row per launch position; a query list longer
   // than the table may hold runs in consecutive chunks of the list (same workspace, same stream).
-  const uint64_t tmax = T ? ph_tiny_max_positions(ix, a.n_layers, a.ef) : 0;
+  // a build's searches first try the table kept across its rounds (tiny.hip): no table pass, and no chunking either
+  bool kept_table = false;
+  if (hint && T && !split) {
+    rc = ph_build_table_prepare(mix, ws, a, *hint, T, stream, &kept_table);
+    if (rc) return rc;
+  }
+  const uint64_t tmax = (T && !kept_table) ? ph_tiny_max_positions(ix, a.n_layers, a.ef) : 0;
   const uint64_t chunk = (tmax && nq > tmax) ? tmax : nq;
   for (uint64_t c0 = 0; c0 < nq; c0 += chunk) {
     PhSearchArgs b = a;
@@ -757,8 +765,10 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
     ws.n_chunks = (uint32_t)(c0 / chunk) + 1;
     PH_HIP(hipEventRecord(ws.evc, stream));  // the dispatch record describes ONE chunk (the last): its clock ...
     if (c0) PH_HIP(hipMemsetAsync(ws.dtotals, 0, sizeof(unsigned long long) * 3 * PH_MAX_DISPATCH, stream));  // ... and counters
-    rc = ph_tiny_prepare(ix, ws, b, T, stream);
-    if (rc) return rc;
+    if (!kept_table) {
+      rc = ph_tiny_prepare(ix, ws, b, T, stream);
+      if (rc) return rc;
+    }
     ws.d_tiny = b.tiny_layers != 0;
     PH_HIP(hipEventRecord(ws.evd[0], stream));
     if (!split) {

@@ -539,9 +539,21 @@ static int ensure_row_dist(phnsw_index *ix, PhLayerHost &L) {
 }
 
 // run the batched search for Stored queries and surface per-query failures
+static PhRowHint row_hint(const PhLayerHost &L, uint32_t first, uint32_t count, bool contiguous) {
+  PhRowHint h;
+  h.qnodes = L.nodes;
+  h.qn = L.n_nodes;
+  h.vec2node = L.identity ? nullptr : L.vec2node;
+  h.first = first;
+  h.count = count;
+  h.contiguous = contiguous;
+  return h;
+}
+
 static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32_t nq, const phnsw_search_params *sp,
                          uint32_t upto, const uint32_t *exclude_dev, uint32_t *out_ids, float *out_d,
-                         uint32_t *out_len, uint32_t out_stride, uint32_t *out_hit, const uint32_t *order = nullptr) {
+                         uint32_t *out_len, uint32_t out_stride, uint32_t *out_hit, const uint32_t *order = nullptr,
+                         const PhRowHint *hint = nullptr) {
   if (sp->number_of_candidates == 0 || sp->number_of_candidates > 1024 || sp->probe_depth == 0) {
     ph_set_error("build: search parameters out of range (number_of_candidates 1..1024, probe_depth >= 1)");
     return PHNSW_E_INVALID;
@@ -551,7 +563,7 @@ static int search_stored(const phnsw_index *ix, const uint32_t *qids_dev, uint32
   uint32_t ovf_cap = ph_default_ovf_cap((uint32_t)sp->number_of_candidates);
   for (int attempt = 0; attempt < 3; attempt++) {
     PH_TRY(ph_search_device(ix, nullptr, 0, qids_dev, nq, sp, upto, exclude_dev, out_ids, out_d, out_len, nullptr,
-                            status.p, ovf_cap, 0, 0, out_stride, out_hit, 0.f, 0, 0.f, order));
+                            status.p, ovf_cap, 0, 0, out_stride, out_hit, 0.f, 0, 0.f, order, nullptr, hint));
     PH_HIP(hipDeviceSynchronize());
     std::vector<uint32_t> h(nq);
     PH_HIP(hipMemcpy(h.data(), status.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
@@ -847,8 +859,9 @@ static int layer_init_search_impl(phnsw_index *ix, const phnsw_build_params *bp,
   PH_TRY(bad.alloc(1));
   const uint32_t *order = nullptr;
   PH_TRY(ph_layer_range_order(P->L, first, count, &order));
+  const PhRowHint hint = row_hint(P->L, first, count, true);
   PH_TRY(search_stored(ix, P->L.nodes + first, count, &bp->initial_partition_search, 0, nullptr, res_ids.p, res_d.p,
-                       res_len.p, 0, nullptr, order));
+                       res_len.p, 0, nullptr, order, &hint));
   PH_HIP(hipMemsetAsync(bad.p, 0, 4, 0));
   hipLaunchKernelGGL(ph_init_from_search_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, P->L.nodes + first, count,
                      P->L.n_nodes, P->L.identity ? nullptr : P->L.vec2node, res_ids.p, res_d.p, res_len.p, K, out_ids,
@@ -969,8 +982,9 @@ static int link_search_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_pa
   PhLayerHost &L = ix->layers[lft];
   const uint32_t *order = nullptr;
   PH_TRY(ph_layer_range_order(L, first, count, &order));
+  const PhRowHint hint = row_hint(L, first, count, true);
   return search_stored(ix, L.nodes + first, count, sp, lft + 1, L.nodes + first, out_ids, out_d, out_len,
-                       (uint32_t)link_count, nullptr, order);
+                       (uint32_t)link_count, nullptr, order, &hint);
 }
 
 // link round, phase 2: all proposals -> rows (K5)  lib.rs:1118-1147
@@ -1083,7 +1097,9 @@ static int recall_hits_impl(phnsw_index *ix, uint32_t at, const phnsw_optimizati
     PH_HIP(hipGetLastError());
     PH_TRY(ph_order_by_keys_device(okeys.p, nq, order.p, 0));
   }
-  PH_TRY(search_stored(ix, q + first, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p, order.p));
+  // the sample is the layer's node list itself when every node is sampled, else any of its nodes
+  const PhRowHint hint = row_hint(L, (uint32_t)first, nq, q == L.nodes);
+  PH_TRY(search_stored(ix, q + first, nq, &op->search, 0, nullptr, ids.p, d.p, len.p, 1, hit.p, order.p, &hint));
   std::vector<uint32_t> h(nq);
   PH_HIP(hipMemcpy(h.data(), hit.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
   uint64_t relevant = 0;
@@ -1158,8 +1174,9 @@ static int discover_hits_impl(phnsw_index *ix, uint32_t lft, const phnsw_search_
   const uint32_t *order = nullptr;
   PH_TRY(ph_layer_range_order(L, first, count, &order));
   for (int attempt = 0; attempt < 3; attempt++) {
+    const PhRowHint hint = row_hint(L, first, count, true);
     PH_TRY(ph_search_device(ix, nullptr, 0, L.nodes + first, count, sp, lft + 1, nullptr, ids.p, d.p, len.p, nullptr,
-                            status.p, ovf_cap, 0, 0, 1, hit_dev, 0.f, 0, 1e-5f, order));
+                            status.p, ovf_cap, 0, 0, 1, hit_dev, 0.f, 0, 1e-5f, order, nullptr, &hint));
     PH_HIP(hipDeviceSynchronize());
     std::vector<uint32_t> hs(count);
     PH_HIP(hipMemcpy(hs.data(), status.p, (size_t)count * 4, hipMemcpyDeviceToHost));
@@ -1443,6 +1460,7 @@ static int promote_at_layer_impl(phnsw_index *ix, uint32_t lft, const phnsw_buil
     for (uint32_t i = 0; i < retop_upto; i++) ph_layer_free(ix->layers[i]);
     for (size_t i = retop_upto; i < ix->layers.size(); i++) nl.push_back(ix->layers[i]);
     ix->layers = nl;
+    ix->nodes_epoch++;
     phnsw_index_destroy(nt);
     offset = new_top_len;
   }
@@ -1522,6 +1540,16 @@ static int improve_index_impl(phnsw_index *ix, const phnsw_build_params *bp, flo
 
 // ------------------------------------------------------------------ C ABI
 
+// the table kept across the rounds of a build lives for the duration of the call that builds (tiny.hip)
+struct BuildTableScope {
+  phnsw_index *ix;
+  explicit BuildTableScope(phnsw_index *i) : ix(i) { ix->bt_enabled = true; }
+  ~BuildTableScope() {
+    ix->bt_enabled = false;
+    ph_build_table_free(ix);
+  }
+};
+
 static int enter(const phnsw_index *ix) {
   if (!ix) {
     ph_set_error("null index");
@@ -1555,6 +1583,7 @@ extern "C" int phnsw_improve_neighbors_upto(phnsw_index *ix, uint32_t upto, cons
                                             float last_recall, float *out_recall) try {
   PH_TRY(enter(ix));
   if (!bp || !out_recall) return PHNSW_E_INVALID;
+  BuildTableScope scope(ix);
   return improve_neighbors_upto_impl(ix, upto, bp, last_recall, out_recall);
 } catch (...) { return ph_caught(); }
 
@@ -1562,6 +1591,7 @@ extern "C" int phnsw_improve_index(phnsw_index *ix, const phnsw_build_params *bp
                                    phnsw_progress_cb cb, void *user, float *out_recall) try {
   PH_TRY(enter(ix));
   if (!bp) return PHNSW_E_INVALID;
+  BuildTableScope scope(ix);
   return improve_index_impl(ix, bp, last_recall, cb, user, out_recall);
 } catch (...) { return ph_caught(); }
 
@@ -1677,6 +1707,7 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
   ix->store = s;
   s->refcount++;
   ix->bp = *bp;
+  ix->bt_enabled = true;  // until the build is done (below): the dense table is kept across the rounds of a layer
   std::vector<uint64_t> vs(vids, vids + n);
   ph_shuffle_u64(vs.data(), n, bp->seed);  // vs.shuffle(&mut thread_rng())  lib.rs:832-833
   std::vector<uint64_t> parts = calculate_partitions(n, bp->order);
@@ -1706,6 +1737,8 @@ static int build_impl(phnsw_store *s, const uint64_t *vids, uint64_t n, const ph
     }
     i++;
   }
+  ix->bt_enabled = false;
+  ph_build_table_free(ix);
   *out = ix;
   return 0;
 }

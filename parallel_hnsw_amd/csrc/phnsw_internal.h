@@ -139,11 +139,35 @@ struct PhWorkspace {
   bool d_tiny = false;
 };
 
+// The dense distance table of the BUILD's searches, kept across rounds (tiny.hip).  A link round, a recall estimate and
+// discover_unreachable all search with Stored(node of layer X) queries, and the distance of such a node to the nodes
+// of the table layer does not change between rounds: row r = node r of layer X, computed once, reused until a node
+// list changes (epoch).  17 % of a 1M build's GPU time was recomputing it every round.
+struct PhBuildTable {
+  float *D = nullptr;       // rows [lo_alloc, hi_alloc) x stride
+  size_t bytes = 0;
+  const uint32_t *qnodes = nullptr, *tnodes = nullptr;  // identity of layer X and of the table layer
+  uint32_t qn = 0, tn = 0, T = 0, stride = 0;
+  uint32_t lo_alloc = 0, hi_alloc = 0, lo = 0, hi = 0;  // allocated rows; valid rows [lo, hi)
+  uint64_t epoch = 0;
+};
+// which layer the Stored queries of a build search are nodes of (build.hip -> ph_search_device)
+struct PhRowHint {
+  const uint32_t *qnodes;    // device: node list of layer X
+  uint32_t qn;
+  const uint32_t *vec2node;  // device: VectorId -> NodeId of layer X, nullptr = identity
+  uint32_t first, count;     // contiguous: the queries are nodes [first, first + count) of X
+  bool contiguous;           // false: any nodes of X (a recall sample)
+};
+
 struct PhPendingLayer;
 struct PhHostStage;  // hostpath.hip: persistent staging of the host-pointer search entry points
 struct phnsw_index {
   std::vector<PhHostStage *> stages;  // handed out under stage_mutex, one per concurrent host-pointer call
   std::mutex stage_mutex;
+  std::vector<PhBuildTable> bt;  // one per layer whose nodes query; build entry points only (exclusive access to the index)
+  bool bt_enabled = false;    // set for the duration of a build / improve_index call: nothing else may keep 29 GB
+  uint64_t nodes_epoch = 0;   // bumped whenever a layer's node list is created, replaced or dropped
   PhPendingLayer *pending = nullptr;  // layer under construction (phase API, build.hip)
   phnsw_store *store = nullptr;
   std::vector<PhLayerHost> layers;  // top first (src/lib.rs:587)
@@ -223,6 +247,10 @@ struct PhSearchArgs {
   const float *tiny_d;          // [launch positions][tiny_stride]
   const uint32_t *tiny_nbr;     // layer l: [tiny_n][W_l] at tiny_off[l], table ids, PH_EMPTY32 padded
   const uint32_t *tiny_member;  // [tiny_n] bit l = node of layer l; [tiny_n] != 0: layers not nested, table off
+  // tiny_rows != 0: tiny_d is the build's kept table -- the row of a Stored query is its NodeId in layer X
+  // (tiny_row_map: VectorId -> NodeId, nullptr = identity) minus tiny_row_first, not its launch position
+  uint32_t tiny_rows, tiny_row_first;
+  const uint32_t *tiny_row_map;
   uint32_t tiny_off[PH_TINY_MAX_LAYERS];
 };
 
@@ -243,7 +271,8 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
                      uint32_t *out_ids, float *out_d, uint32_t *out_len, uint32_t *out_stats, uint32_t *status,
                      uint32_t ovf_cap, uint32_t knn_mode, hipStream_t stream, uint32_t out_stride = 0,
                      uint32_t *out_hit = nullptr, float threshold = 0.f, uint32_t first_node = 0,
-                     float hit_eps = 0.f, const uint32_t *order = nullptr, uint32_t *out_index = nullptr);
+                     float hit_eps = 0.f, const uint32_t *order = nullptr, uint32_t *out_index = nullptr,
+                     const PhRowHint *hint = nullptr);
 // locality schedule helpers (group.hip / api.hip)
 #define PH_ORDER_MIN 16384u  // shorter query lists run in natural order
 #define PH_POS_MIN 256u     // smaller layers carry no cells (their node id is the key)
@@ -266,6 +295,11 @@ int ph_layer_range_order(PhLayerHost &L, uint32_t first, uint32_t count, const u
 // against a distance table, fills a.tiny_* and enqueues the table kernels for launch positions
 // [0, npos) (position p = query order[p], or p itself) on `stream`.  a.tiny_layers = 0 when unused.
 int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uint32_t max_layers, hipStream_t stream);
+// the build's kept table: rows for the hinted queries are made available (computed where missing) and the launch is
+// pointed at them; *used = false when the table cannot serve this launch (then ph_tiny_prepare does, per launch)
+int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, const PhRowHint &h, uint32_t T,
+                           hipStream_t stream, bool *used);
+void ph_build_table_free(phnsw_index *ix);
 size_t ph_tiny_lds_bytes(const PhSearchArgs &a);
 bool ph_tiny_matrix_cores(const phnsw_index *ix);  // the table of this index's store is built by the MFMA kernel
 uint32_t ph_tiny_layer_count(const phnsw_index *ix, uint32_t n_layers, uint32_t ef);  // leading layers a launch may run densely

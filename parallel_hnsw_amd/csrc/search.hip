@@ -138,6 +138,9 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     if (layer_lo && a.status[q] != ST_OK) continue;  // failed in the first launch: keep its status
     const uint32_t qnode = a.first_node + q;  // knn modes: the query is a node of the bottom layer
     uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[qnode] : (a.qids ? a.qids[q] : 0u);
+    // row of this query in the dense table: its launch position, or (the build's kept table) its NodeId in layer X
+    uint64_t trow = qpos;
+    if (a.tiny_rows) trow = (uint64_t)((a.tiny_row_map ? a.tiny_row_map[qvec] : qvec) - a.tiny_row_first);
     Dist dist;
     if (a.queries && !a.knn_mode)
       dist.prepare_raw(a.dist, a.queries + (uint64_t)q * a.ldq, dist_lds, lane);
@@ -174,7 +177,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       if constexpr (DENSE_ONLY) {  // the table holds it
         const PhLayerDev TLy = a.layers[a.tiny_layers - 1];
         const uint32_t tid = TLy.vec2node ? TLy.vec2node[entry] : entry;
-        d0 = (a.tiny_d + (uint64_t)qpos * a.tiny_stride)[tid < a.tiny_n ? tid : 0u];
+        d0 = (a.tiny_d + trow * a.tiny_stride)[tid < a.tiny_n ? tid : 0u];
       } else {
         d0 = dist.batch(a.dist, 1ull, entry, lane);
       }
@@ -186,7 +189,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       }
       clen = 1;
     }
-    const float *Dg = a.tiny_d + (uint64_t)qpos * a.tiny_stride;  // this query's row of the table
+    const float *Dg = a.tiny_d + trow * a.tiny_stride;  // this query's row of the table
     if (T) {
       if (tiny_lds_row)
         for (uint32_t i = lane; i < a.tiny_n; i += 64) Dl[i] = Dg[i];

@@ -710,6 +710,7 @@ extern "C" int phnsw_build_sharded(phnsw_store *s, const uint64_t *vids, uint64_
   g.bp = *bp;
   g.ix = nullptr;
   PH_TRY(phnsw_index_create(s, bp, &g.ix));
+  g.ix->bt_enabled = true;  // the dense table of a layer's rounds is kept for this rank's node range (tiny.hip)
   phnsw_shard_engine e = gpu_engine(&g);
   int rc;
   {
@@ -721,6 +722,8 @@ extern "C" int phnsw_build_sharded(phnsw_store *s, const uint64_t *vids, uint64_
     d.st.seconds_total = now_s() - t0;
     if (stats) *stats = d.st;
   }
+  g.ix->bt_enabled = false;
+  ph_build_table_free(g.ix);
   ph_pool_trim();
   if (rc) {
     phnsw_index_destroy(g.ix);
@@ -744,7 +747,10 @@ extern "C" int phnsw_improve_index_sharded(phnsw_index *ix, const phnsw_build_pa
   Driver d(&e, comm, bp);
   PH_TRY(d.check());
   double t0 = now_s();
+  ix->bt_enabled = true;
   int rc = d.improve_index(last_recall, out_recall);
+  ix->bt_enabled = false;
+  ph_build_table_free(ix);
   d.st.seconds_total = now_s() - t0;
   if (stats) *stats = d.st;
   return rc;

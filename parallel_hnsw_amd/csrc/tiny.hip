@@ -458,13 +458,9 @@ static hipError_t grow(T **p, size_t *have, size_t need) {
   return e;
 }
 
-int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uint32_t max_layers, hipStream_t stream) {
-  a.tiny_layers = 0;
-  if (a.knn_mode || a.layer_lo) return 0;
-  uint32_t T = std::min(ph_tiny_layer_count(ix, a.n_layers, a.ef), max_layers);
-  if (!T) return 0;
-  const uint32_t tn = ix->layers[T - 1].n_nodes, stride = tiny_stride_of(tn), npos = a.nq;
-  if ((uint64_t)npos > ph_tiny_max_positions(ix, a.n_layers, a.ef)) return 0;  // the caller chunks; never reached through api.hip
+// the neighbour rows of the dense layers rewritten in table ids + the membership mask (per launch: the rows change
+// between build rounds)
+static int tiny_prep_graph(PhWorkspace &ws, PhSearchArgs &a, uint32_t T, uint32_t tn, hipStream_t stream) {
   PhTinyPrepArgs p;
   memset(&p, 0, sizeof(p));
   p.T = T;
@@ -476,13 +472,10 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
     a.tiny_off[l] = (uint32_t)nbr_words;
     nbr_words += (size_t)tn * a.layers[l].W;
   }
-  // the table is an accelerator, never a requirement: when the device cannot spare it the launch simply walks
-  // every layer on the per-hop path (same results)
-  if (grow(&ws.tiny_d, &ws.tiny_d_bytes, std::max<size_t>((size_t)npos * stride * 4u, 1u << 20)) != hipSuccess ||
-      grow(&ws.tiny_nbr, &ws.tiny_nbr_bytes, nbr_words * 4u) != hipSuccess ||
+  if (grow(&ws.tiny_nbr, &ws.tiny_nbr_bytes, nbr_words * 4u) != hipSuccess ||
       grow(&ws.tiny_member, &ws.tiny_member_bytes, (size_t)(PH_TINY_MAX_NODES + 1u) * 4u) != hipSuccess) {
     (void)hipGetLastError();
-    return 0;
+    return 1;  // not an error: the launch walks every layer on the per-hop path
   }
   p.nbr = ws.tiny_nbr;
   p.member = ws.tiny_member;
@@ -490,49 +483,57 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
   PH_HIP(hipMemsetAsync(ws.tiny_member, 0, (size_t)(tn + 1u) * 4u, stream));
   hipLaunchKernelGGL(ph_tiny_prep_kernel, dim3((tn + 255u) / 256u, T), dim3(256), 0, stream, p);
   PH_HIP(hipGetLastError());
+  return 0;
+}
 
+// D[p][t] = compare_vec(query of position p, Stored(tnodes[t])) for npos positions (position p = query order[p], or p
+// itself; raw queries or Stored ids), the per-hop path's bits: the matrix-core kernel where it applies, else the
+// vector-unit tile pass.  returns 1 (no error set) when its operand buffers cannot be allocated.
+static int tiny_table(PhWorkspace &ws, const PhDistArgs &dist, const float *queries, uint32_t ldq, const uint32_t *qids,
+                      const uint32_t *order, uint32_t npos, const uint32_t *tnodes, uint32_t tn, uint32_t stride, float *D,
+                      hipStream_t stream) {
   PhTinyTableArgs t;
   memset(&t, 0, sizeof(t));
-  t.dist = a.dist;
-  t.queries = a.queries;
-  t.ldq = a.ldq;
-  t.qids = a.qids;
-  t.order = a.order;
+  t.dist = dist;
+  t.queries = queries;
+  t.ldq = ldq;
+  t.qids = qids;
+  t.order = order;
   t.npos = npos;
-  t.tnodes = a.layers[T - 1].nodes;
+  t.tnodes = tnodes;
   t.tiny_n = tn;
   t.stride = stride;
-  t.D = ws.tiny_d;
+  t.D = D;
   if (const char *e = getenv("PHNSW_TINY_DBG")) t.dbg = (uint32_t)atoi(e);
-  const uint32_t nv4 = a.dist.nv4;
+  const uint32_t nv4 = dist.nv4;
   const int nv = nv4 <= 64 ? 1 : (nv4 <= 192 ? 3 : 6);
   // dot-product metrics over whole 64-chunk rows go to the matrix cores (same bits, see above); the Euclidean
   // chain (fma(d, d, acc) of a difference) is not a product of the two operands and stays on the vector units, as
   // do ragged rows and launches of a handful of queries.  PHNSW_TINY_VALU=1 forces the vector kernel (tests).
-  const bool mfma = tiny_mfma_shape(a.dist.metric, nv4 * 4u) && nv4 == 64u * (uint32_t)nv && npos >= 32u;
+  const bool mfma = tiny_mfma_shape(dist.metric, nv4 * 4u) && nv4 == 64u * (uint32_t)nv && npos >= 32u;
   if (mfma) {
     const uint32_t qtiles = (npos + 63u) / 64u, ntiles = (tn + 63u) / 64u;
     const size_t row_bytes = (size_t)nv * 64u * sizeof(float4);
     if (grow(&ws.tiny_pq, &ws.tiny_pq_bytes, (size_t)qtiles * 64u * row_bytes) != hipSuccess ||
         grow(&ws.tiny_pn, &ws.tiny_pn_bytes, (size_t)ntiles * 64u * row_bytes) != hipSuccess) {
       (void)hipGetLastError();
-      return 0;
+      return 1;
     }
     PhTinyPackArgs k;
     memset(&k, 0, sizeof(k));
-    k.vecs = a.dist.vecs;
-    k.ld = a.dist.ld;
+    k.vecs = dist.vecs;
+    k.ld = dist.ld;
     k.nv = (uint32_t)nv;
-    k.queries = a.queries;
-    k.ldq = a.ldq;
-    k.ids = a.qids;
-    k.order = a.order;
+    k.queries = queries;
+    k.ldq = ldq;
+    k.ids = qids;
+    k.order = order;
     k.n = npos;
     k.n_pad = qtiles * 64u;
     k.out = ws.tiny_pq;
     hipLaunchKernelGGL(ph_tiny_pack_kernel, dim3(k.n_pad / 32u, 8u * (uint32_t)nv), dim3(32, 8), 0, stream, k);
     k.queries = nullptr;
-    k.ids = a.layers[T - 1].nodes;
+    k.ids = tnodes;
     k.order = nullptr;
     k.n = tn;
     k.n_pad = ntiles * 64u;
@@ -548,8 +549,8 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
     m.stride = stride;
     m.qtiles = qtiles;
     m.ntiles = ntiles;
-    m.metric = a.dist.metric;
-    m.D = ws.tiny_d;
+    m.metric = dist.metric;
+    m.D = D;
     const uint32_t supers = ((qtiles + 7u) / 8u) * ((ntiles + 7u) / 8u);
     const uint32_t blocks = (supers + 7u) / 8u * 8u * 64u;
     constexpr int G = 2;
@@ -563,26 +564,163 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
       hipLaunchKernelGGL((ph_tiny_table_mfma_kernel<6, G>), dim3(blocks), dim3(256), lds, stream, m);
     }
   } else {
-  const uint32_t qt = nv == 6 ? 4u : 8u;
-  const uint32_t gx = (npos + 4u * qt - 1u) / (4u * qt);
-  const uint32_t tiles = (tn + 7u) / 8u;
-  uint32_t slices = std::min<uint32_t>(tiles, std::max<uint32_t>(1u, (2048u + gx - 1u) / gx));
-  t.rows_per_slice = (tiles + slices - 1u) / slices * 8u;
-  slices = (tn + t.rows_per_slice - 1u) / t.rows_per_slice;
-  dim3 grid(gx, slices);
-  if (nv == 1)
-    hipLaunchKernelGGL((ph_tiny_table_kernel<1, 8>), grid, dim3(256), 0, stream, t);
-  else if (nv == 3)
-    hipLaunchKernelGGL((ph_tiny_table_kernel<3, 8>), grid, dim3(256), 0, stream, t);
-  else
-    hipLaunchKernelGGL((ph_tiny_table_kernel<6, 4>), grid, dim3(256), 0, stream, t);
+    const uint32_t qt = nv == 6 ? 4u : 8u;
+    const uint32_t gx = (npos + 4u * qt - 1u) / (4u * qt);
+    const uint32_t tiles = (tn + 7u) / 8u;
+    uint32_t slices = std::min<uint32_t>(tiles, std::max<uint32_t>(1u, (2048u + gx - 1u) / gx));
+    t.rows_per_slice = (tiles + slices - 1u) / slices * 8u;
+    slices = (tn + t.rows_per_slice - 1u) / t.rows_per_slice;
+    dim3 grid(gx, slices);
+    if (nv == 1)
+      hipLaunchKernelGGL((ph_tiny_table_kernel<1, 8>), grid, dim3(256), 0, stream, t);
+    else if (nv == 3)
+      hipLaunchKernelGGL((ph_tiny_table_kernel<3, 8>), grid, dim3(256), 0, stream, t);
+    else
+      hipLaunchKernelGGL((ph_tiny_table_kernel<6, 4>), grid, dim3(256), 0, stream, t);
   }
   PH_HIP(hipGetLastError());
+  return 0;
+}
+
+int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uint32_t max_layers, hipStream_t stream) {
+  a.tiny_layers = 0;
+  a.tiny_rows = 0;
+  if (a.knn_mode || a.layer_lo) return 0;
+  uint32_t T = std::min(ph_tiny_layer_count(ix, a.n_layers, a.ef), max_layers);
+  if (!T) return 0;
+  const uint32_t tn = ix->layers[T - 1].n_nodes, stride = tiny_stride_of(tn), npos = a.nq;
+  if ((uint64_t)npos > ph_tiny_max_positions(ix, a.n_layers, a.ef)) return 0;  // the caller chunks; never reached through api.hip
+  // the table is an accelerator, never a requirement: when the device cannot spare it the launch simply walks
+  // every layer on the per-hop path (same results)
+  if (grow(&ws.tiny_d, &ws.tiny_d_bytes, std::max<size_t>((size_t)npos * stride * 4u, 1u << 20)) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int rc = tiny_prep_graph(ws, a, T, tn, stream);
+  if (rc) return rc < 0 ? rc : 0;
+  rc = tiny_table(ws, a.dist, a.queries, a.ldq, a.qids, a.order, npos, a.layers[T - 1].nodes, tn, stride, ws.tiny_d, stream);
+  if (rc) return rc < 0 ? rc : 0;
   a.tiny_layers = T;
   a.tiny_n = tn;
   a.tiny_stride = stride;
   a.tiny_d = ws.tiny_d;
   a.tiny_nbr = ws.tiny_nbr;
   a.tiny_member = ws.tiny_member;
+  return 0;
+}
+
+// ------------------------------------------------------------------ the build's kept table
+
+void ph_build_table_free(phnsw_index *ix) {
+  for (PhBuildTable &b : ix->bt)
+    if (b.D) hipFree(b.D);
+  ix->bt.clear();
+}
+static void build_table_drop(PhBuildTable &b) {  // the rows go, the slot (which layer it belongs to) stays
+  if (b.D) hipFree(b.D);
+  b.D = nullptr;
+  b.bytes = 0;
+  b.lo = b.hi = b.lo_alloc = b.hi_alloc = 0;
+}
+
+// rows kept only for table layers of at least this many nodes (smaller tables cost less than the bookkeeping);
+// PHNSW_BUILD_TABLE_MIN overrides (the tests keep every table), PHNSW_NO_BUILD_TABLE=1 switches the cache off
+static uint32_t build_table_min() {
+  if (const char *e = getenv("PHNSW_BUILD_TABLE_MIN"))
+    if (atoi(e) > 0) return (uint32_t)atoi(e);
+  return 1024u;
+}
+
+int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, const PhRowHint &h, uint32_t T,
+                           hipStream_t stream, bool *used) {
+  *used = false;
+  a.tiny_rows = 0;
+  if (!ix->bt_enabled || !T || !a.qids || a.queries || a.knn_mode || a.layer_lo || getenv("PHNSW_NO_BUILD_TABLE")) return 0;
+  const uint32_t tn = ix->layers[T - 1].n_nodes, stride = tiny_stride_of(tn);
+  const uint32_t *tnodes = a.layers[T - 1].nodes;
+  if (tn < build_table_min() || h.qn == 0) return 0;
+  // one table per querying layer (an outer round of improve_neighbors_upto links every layer in turn); a changed node
+  // list anywhere (epoch) voids them all
+  if (!ix->bt.empty() && ix->bt[0].epoch != ix->nodes_epoch) ph_build_table_free(ix);
+  PhBuildTable *found = nullptr;
+  for (PhBuildTable &b : ix->bt)
+    if (b.qnodes == h.qnodes && b.qn == h.qn) found = &b;
+  if (!found) {
+    if (ix->bt.size() >= PH_MAX_LAYERS) return 0;
+    ix->bt.emplace_back();
+    found = &ix->bt.back();
+    found->epoch = ix->nodes_epoch;
+    found->qnodes = h.qnodes;
+    found->qn = h.qn;
+  }
+  PhBuildTable &B = *found;
+  const uint32_t need_lo = h.contiguous ? h.first : 0u, need_hi = h.contiguous ? h.first + h.count : h.qn;
+  if (need_hi > h.qn || need_lo >= need_hi) return 0;
+  const bool same = B.D && B.tnodes == tnodes && B.tn == tn && B.T == T;
+  if (B.D && !same) build_table_drop(B);
+  if (!h.contiguous && !(B.D && B.lo <= need_lo && B.hi >= need_hi)) return 0;  // a sample: only from rows already there
+  if (!B.D || need_lo < B.lo_alloc || need_hi > B.hi_alloc) {
+    // (re)allocate for the requested range: the whole layer on one GPU, a rank's node range in a sharded build
+    if (B.D && (need_lo > B.lo_alloc || need_hi < B.hi_alloc)) return 0;  // a second, different range: not worth juggling
+    build_table_drop(B);
+    const size_t bytes = (size_t)(need_hi - need_lo) * stride * 4u;
+    size_t mfree = 0, mtotal = 0;
+    PH_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if (bytes + (8ull << 30) > mfree || bytes > mtotal / 2) return 0;  // the searches' own workspaces come first
+    if (hipMalloc(&B.D, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      B.D = nullptr;
+      return 0;
+    }
+    B.bytes = bytes;
+    B.qnodes = h.qnodes;
+    B.qn = h.qn;
+    B.tnodes = tnodes;
+    B.tn = tn;
+    B.T = T;
+    B.stride = stride;
+    B.lo_alloc = need_lo;
+    B.hi_alloc = need_hi;
+    B.lo = B.hi = need_lo;
+    B.epoch = ix->nodes_epoch;
+  }
+  // rows missing from [need_lo, need_hi): the valid rows are one interval; fill what lies outside it
+  auto fill = [&](uint32_t lo, uint32_t hi) -> int {
+    const uint32_t PIECE = 131072u;  // bounds the packed-operand buffer (400 MB at 768 floats)
+    for (uint32_t at = lo; at < hi; at += PIECE) {
+      const uint32_t cnt = std::min(PIECE, hi - at);
+      int rc = tiny_table(ws, a.dist, nullptr, 0, h.qnodes + at, nullptr, cnt, tnodes, tn, stride,
+                          B.D + (size_t)(at - B.lo_alloc) * stride, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  };
+  int rc = 0;
+  if (B.lo == B.hi) {
+    rc = fill(need_lo, need_hi);
+    if (!rc) B.lo = need_lo, B.hi = need_hi;
+  } else {
+    if (need_lo < B.lo) {
+      rc = fill(need_lo, B.lo);
+      if (!rc) B.lo = need_lo;
+    }
+    if (!rc && need_hi > B.hi) {
+      rc = fill(B.hi, need_hi);
+      if (!rc) B.hi = need_hi;
+    }
+  }
+  if (rc) return rc < 0 ? rc : 0;
+  rc = tiny_prep_graph(ws, a, T, tn, stream);
+  if (rc) return rc < 0 ? rc : 0;
+  a.tiny_layers = T;
+  a.tiny_n = tn;
+  a.tiny_stride = stride;
+  a.tiny_d = B.D;
+  a.tiny_rows = 1;
+  a.tiny_row_first = B.lo_alloc;
+  a.tiny_row_map = h.vec2node;
+  a.tiny_nbr = ws.tiny_nbr;
+  a.tiny_member = ws.tiny_member;
+  *used = true;
   return 0;
 }
