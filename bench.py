@@ -244,10 +244,23 @@ def worker(args):
         threading.Thread(target=watchdog, daemon=True).start()
         out = {}
         try:
-            comm = ph.TorchComm()
-            cc = comm.c_comm(local)   # nccl backend: phnsw_comm_rccl_create, the id travels through the group
             from parallel_hnsw_amd._lib import check
-            check(ph.lib().phnsw_comm_selftest(cc, 1 << 20))
+            comm, transport, ok = ph.TorchComm(), None, 1
+            try:
+                cc = comm.c_comm(local)   # nccl backend: phnsw_comm_rccl_create, the id travels through the group
+                check(ph.lib().phnsw_comm_selftest(cc, 1 << 20))
+                transport = "phnsw_comm_rccl (ncclAllGather)" if backend == "nccl" else "host callbacks (%s)" % backend
+            except Exception as exc:  # an error (a hang is the watchdog's business): every rank must learn of it
+                ok = 0
+                log("the library's RCCL transport failed on rank %d: %r" % (rank, exc))
+            t = torch.tensor([ok], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                # fall back to the host-callback transport over a gloo group: slower on the wire, same driver, same graph
+                comm = ph.TorchComm(dist.new_group(backend="gloo"))
+                cc = comm.c_comm(local)
+                check(ph.lib().phnsw_comm_selftest(cc, 1 << 16))
+                transport = "host callbacks over a gloo group (the RCCL transport failed its self-test: see stderr)"
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.time()
@@ -261,9 +274,9 @@ def worker(args):
                 same = same and np.array_equal(a_.nodes, b_.nodes) and np.array_equal(a_.neighbors, b_.neighbors)
             out = {"ranks": world, "seconds": round(secs, 3), "vectors_per_s": round(store.n / secs, 1),
                    "identical_to_single_gpu_build": bool(same),
-                   "driver": "phnsw_build_sharded (C ABI) over %s" % ("phnsw_comm_rccl (ncclAllGather)" if backend == "nccl"
-                                                                      else "host callbacks (%s)" % backend),
-                   "rank0_seconds": {k: round(v, 4) for k, v in st.items() if k.startswith("seconds")},
+                   "driver": "phnsw_build_sharded (C ABI) over %s" % transport,
+                   "rank0_seconds": {k: round(v, 4) for k, v in st.items() if k.startswith("seconds") and k != "seconds_by_phase"},
+                   "rank0_seconds_by_phase": {k: round(v, 4) for k, v in st["seconds_by_phase"].items()},
                    "phases": st["phases"], "phases_not_split": st["phases_whole"],
                    "all_gather": {"bytes_received_per_rank": st["all_gather_bytes"], "collectives": st["all_gather_calls"],
                                   "host_seconds_in_collectives_waits_and_reassembly": round(st["seconds_comm"], 4),
