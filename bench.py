@@ -799,7 +799,7 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
         pst = torch.empty((nq, 2), dtype=torch.int32, device=dev)
         pstatus = torch.empty(nq, dtype=torch.int32, device=dev)
         best, cells = None, []
-        for ef, pdp in [(128, 8), (256, 8), (384, 8), (448, 8), (512, 8), (512, 16)]:
+        for ef, pdp in [(128, 8), (256, 8), (384, 8), (416, 8), (432, 8), (448, 8), (512, 8), (512, 16)]:
             spq = ph.SearchParameters(ef, ef, pdp)
             for _ in range(2):
                 torch.cuda.synchronize()
