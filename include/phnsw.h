@@ -486,7 +486,8 @@ int phnsw_bruteforce_topk_device(const phnsw_store *s, const float *queries_dev,
 float phnsw_bruteforce_last_gemm_ms(void); /* MFMA GEMM time of this thread's last pass */
 
 /* Hnsw::threshold_nn  src/lib.rs:930-962 : bottom layer; out [node_count][max_out], entries
- * with distance < threshold, self removed; the device queue may double up to 1024 entries */
+ * with distance < threshold, self removed.  The queue doubles without bound like the reference's
+ * (resize_capacity, lib.rs:949-951): in LDS up to 1024 entries, in global memory beyond. */
 int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,
                        uint64_t initial_search_depth, uint64_t max_out, uint64_t *out_ids,
                        float *out_d, uint64_t *out_len);

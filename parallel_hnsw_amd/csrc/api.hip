@@ -996,16 +996,155 @@ extern "C" int phnsw_knn(const phnsw_index *ix, uint64_t k, uint64_t probe_depth
   return 0;
 } catch (...) { return ph_caught(); }
 
+namespace {
+// device scratch that grows to the largest request and is released with its owner
+template <class T>
+struct GrowBuf {
+  T *p = nullptr;
+  size_t have = 0;
+  int alloc(size_t count) {
+    count = std::max<size_t>(count, 1);
+    if (have >= count) return 0;
+    if (p) hipFree(p);
+    p = nullptr;
+    have = 0;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) return ph_hip_fail(e, "hipMalloc (threshold_nn)", __FILE__, __LINE__);
+    have = count;
+    return 0;
+  }
+  ~GrowBuf() {
+    if (p) hipFree(p);
+  }
+  GrowBuf() = default;
+  GrowBuf(const GrowBuf &) = delete;
+  GrowBuf &operator=(const GrowBuf &) = delete;
+};
+}  // namespace
+#define PH_TRY_(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+
+// threshold_nn for the nodes whose queue outgrew LDS: the same search from the start with the queue in global memory
+// (ph_search_kernel_big), its capacity doubled from launch to launch until nobody asks for more.  A queue never
+// holds more than the layer's nodes, so a capacity of twice that is final.
+static int threshold_nn_big(const phnsw_index *ix, const phnsw_search_params *sp, float threshold, std::vector<uint32_t> nodes,
+                            const std::vector<uint32_t> &h_nodes, uint64_t max_out, uint64_t *out_ids, float *out_d,
+                            uint64_t *out_len) {
+  const PhLayerHost &L = ix->layers.back();
+  const uint32_t n = L.n_nodes;
+  const uint64_t isd = sp->number_of_candidates;
+  const uint32_t os = (uint32_t)std::min<uint64_t>(max_out + 2, (uint64_t)n + 1);  // self + max_out + one more to tell "too many"
+  const uint64_t words = ((uint64_t)n + 31) / 32 + 1;
+  uint64_t cap = isd * 2;  // capacities follow the queue's own doubling sequence
+  while (cap <= 1024) cap *= 2;
+  GrowBuf<uint32_t> d_nodes, d_vis, d_q, d_oid, d_len, d_status, d_counter;
+  GrowBuf<float> d_od;
+  GrowBuf<uint2> d_ovf;
+  std::vector<uint32_t> h_ids, h_len, h_status;
+  std::vector<float> h_d;
+  while (!nodes.empty()) {
+    if (cap > 0x7FFFFFFFull) {
+      ph_set_error("threshold_nn: queue capacity beyond 2^31");
+      return PHNSW_E_UNSUPPORTED;
+    }
+    const bool final_cap = cap >= 2ull * n;
+    // resident waves: what 4 GiB of queues, spill lists (a layer's nodes at most) and visited bits allow
+    const uint64_t per_slot = cap * 8 + (uint64_t)n * 8 + words * 4;
+    uint64_t budget = 4ull << 30;
+    if (const char *e = getenv("PHNSW_THRESHOLD_BIG_BYTES")) budget = strtoull(e, nullptr, 10);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nodes.size(), 1024), std::max<uint64_t>(1, budget / per_slot));
+    const size_t cnt = nodes.size();
+    PH_TRY_(d_nodes.alloc(cnt));
+    PH_TRY_(d_oid.alloc(cnt * os));
+    PH_TRY_(d_od.alloc(cnt * os));
+    PH_TRY_(d_len.alloc(cnt));
+    PH_TRY_(d_status.alloc(cnt));
+    PH_TRY_(d_counter.alloc(128));
+    PH_TRY_(d_vis.alloc((size_t)grid * words));
+    PH_TRY_(d_ovf.alloc((size_t)grid * n));
+    PH_TRY_(d_q.alloc((size_t)grid * 2 * cap));
+    PH_HIP(hipMemset(d_vis.p, 0, (size_t)grid * words * 4));
+    PH_HIP(hipMemcpy(d_nodes.p, nodes.data(), cnt * 4, hipMemcpyHostToDevice));
+    PhSearchArgs a;
+    fill_args(ix, sp, 0, a);
+    a.nq = (uint32_t)cnt;
+    a.out_ids = d_oid.p;
+    a.out_d = d_od.p;
+    a.out_len = d_len.p;
+    a.status = d_status.p;
+    a.knn_mode = 2;
+    a.threshold = threshold;
+    a.out_stride = os;
+    a.cap_max = (uint32_t)cap;
+    a.knn_nodes = d_nodes.p;
+    a.big_q = d_q.p;
+    a.visited = d_vis.p;
+    a.visited_words = words;
+    a.ovf = d_ovf.p;
+    a.ovf_cap = n;
+    a.counter = d_counter.p;
+    PH_TRY_(ph_search_launch_big(ix, a, grid, 0));
+    PH_HIP(hipDeviceSynchronize());
+    h_ids.resize(cnt * os);
+    h_d.resize(cnt * os);
+    h_len.resize(cnt);
+    h_status.resize(cnt);
+    PH_HIP(hipMemcpy(h_ids.data(), d_oid.p, cnt * os * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(h_d.data(), d_od.p, cnt * os * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(h_len.data(), d_len.p, cnt * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(h_status.data(), d_status.p, cnt * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> again;
+    for (size_t x = 0; x < cnt; x++) {
+      const uint64_t i = nodes[x];
+      if (h_status[x] == 6 && !final_cap) {  // ST_CAPACITY: once more with twice the queue
+        again.push_back(nodes[x]);
+        continue;
+      }
+      if (h_status[x]) {
+        ph_set_error("threshold_nn: node %llu failed with status %u at a queue capacity of %llu", (unsigned long long)i,
+                     h_status[x], (unsigned long long)cap);
+        return PHNSW_E_OVERFLOW;
+      }
+      uint64_t o = 0;
+      for (uint32_t j = 0; j < h_len[x]; j++) {
+        const uint32_t v = h_ids[x * os + j];
+        const float d = h_d[x * os + j];
+        if (v == h_nodes[i]) continue;  // filter(|(n,_)| *n != node)
+        if (!(d < threshold)) break;    // take_while(distance < threshold)
+        if (o == max_out) {
+          ph_set_error("threshold_nn: node %llu has more than max_out=%llu results", (unsigned long long)i,
+                       (unsigned long long)max_out);
+          return PHNSW_E_OVERFLOW;
+        }
+        out_ids[i * max_out + o] = v;
+        out_d[i * max_out + o] = d;
+        o++;
+      }
+      out_len[i] = o;
+      for (; o < max_out; o++) {
+        out_ids[i * max_out + o] = PHNSW_EMPTY;
+        out_d[i * max_out + o] = PH_FMAX;
+      }
+    }
+    nodes.swap(again);
+    cap *= 2;
+  }
+  return 0;
+}
+
 // Hnsw::threshold_nn  src/lib.rs:930-962: per bottom-layer node a queue seeded with
 // (self, 0.0) that doubles (resize_capacity) until its last entry reaches the threshold;
-// result = entries below the threshold without self.  Nodes are processed in chunks; the
-// queue may grow to 1024 entries on the device.
+// result = entries below the threshold without self.  Nodes are processed in chunks with the
+// queue in LDS (up to 1024 entries); a node that needs more goes through threshold_nn_big.
 extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64_t probe_depth,
                                   uint64_t initial_search_depth, uint64_t max_out, uint64_t *out_ids, float *out_d,
                                   uint64_t *out_len) try {
   if (!ix || ix->layers.empty() || !out_ids || !out_d || !out_len || initial_search_depth == 0 ||
-      initial_search_depth > 1024 || probe_depth == 0 || max_out == 0) {
-    ph_set_error("phnsw_threshold_nn: initial_search_depth must be 1..1024, probe_depth >= 1");
+      initial_search_depth > 0x40000000ull || probe_depth == 0 || max_out == 0) {
+    ph_set_error("phnsw_threshold_nn: initial_search_depth and probe_depth must be >= 1");
     return PHNSW_E_INVALID;
   }
   const phnsw_store *s = ix->store;
@@ -1015,6 +1154,12 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   phnsw_search_params sp = {initial_search_depth, initial_search_depth, probe_depth};
   std::vector<uint32_t> h_nodes(n);
   PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> big;  // nodes whose queue has to grow past CAPMAX
+  if (initial_search_depth > CAPMAX || getenv("PHNSW_THRESHOLD_ALL_BIG")) {
+    big.resize(n);
+    for (uint32_t i = 0; i < n; i++) big[i] = i;
+    return threshold_nn_big(ix, &sp, threshold, std::move(big), h_nodes, max_out, out_ids, out_d, out_len);
+  }
   uint32_t *oid = nullptr, *olen = nullptr, *ostat = nullptr;
   float *od = nullptr;
   uint32_t cn = std::min(n, CHUNK);
@@ -1041,10 +1186,13 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
     }
     for (uint32_t x = 0; x < cnt && !rc; x++) {
       uint64_t i = first + x;
+      if (h_status[x] == 6) {  // ST_CAPACITY
+        big.push_back((uint32_t)i);
+        continue;
+      }
       if (h_status[x]) {
-        ph_set_error("threshold_nn: node %llu %s", (unsigned long long)i,
-                     h_status[x] == 6 ? "needs a queue beyond 1024 entries" : "overflowed the frontier workspace");
-        rc = h_status[x] == 6 ? PHNSW_E_UNSUPPORTED : PHNSW_E_OVERFLOW;
+        ph_set_error("threshold_nn: node %llu overflowed the frontier workspace", (unsigned long long)i);
+        rc = PHNSW_E_OVERFLOW;
         break;
       }
       uint64_t o = 0;
@@ -1074,5 +1222,6 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (od) hipFree(od);
   if (olen) hipFree(olen);
   if (ostat) hipFree(ostat);
+  if (!rc && !big.empty()) rc = threshold_nn_big(ix, &sp, threshold, std::move(big), h_nodes, max_out, out_ids, out_d, out_len);
   return rc;
 } catch (...) { return ph_caught(); }

@@ -210,6 +210,10 @@ struct PhSearchArgs {
   float threshold;
   uint32_t first_node;  // knn modes: queries are nodes first_node .. first_node + nq
   uint32_t cap_max;     // threshold_nn: largest queue capacity the launch must support (0 = ef)
+  // threshold_nn beyond the LDS queues (ph_search_kernel_big): an explicit node list and, per resident wave, a
+  // queue of cap_max (id, distance) slots in global memory
+  const uint32_t *knn_nodes;
+  uint32_t *big_q;
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
   unsigned long long *totals;   // nullable: [2] running sums of distance evaluations / hops (all launches)
@@ -309,6 +313,8 @@ void ph_tiny_free(PhWorkspace &ws);
 // launchers (search.hip)
 int ph_search_begin(PhWorkspace &ws, hipStream_t stream);
 int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hipStream_t stream, bool mark_end = true);
+// threshold_nn's global-memory queues: `a` complete (visited / ovf / counter / big_q are the caller's, `grid` slots each)
+int ph_search_launch_big(const phnsw_index *ix, PhSearchArgs &a, uint32_t grid, hipStream_t stream);
 int ph_workspace_order_ensure(PhWorkspace &ws, uint32_t nq);                          // group.hip
 int ph_workspace_order_sort(PhWorkspace &ws, uint32_t nq, hipStream_t stream);        // group.hip
 void ph_workspace_order_free(PhWorkspace &ws);                                        // group.hip

@@ -60,7 +60,17 @@
 // value returned is the index_sum of the node expanded at the last hop of the bottom layer that changed
 // candidates.first() (lib.rs:225-231).  The sums ride along in a third queue array (the prefix scratch S, idle
 // during the hops) and a parallel spill array; the plain kernels compile none of it.
-template <int CAPC, class Dist, bool INSTR = false>
+// BIG (threshold_nn only, ph_search_kernel_big): the layer queue lives in global memory with a capacity chosen at
+// launch (a.cap_max), so resize_capacity can go on doubling past what LDS holds.  The queue is then shared between
+// the lanes of the wave through L2: every barrier of the body also orders and invalidates (queue_sync), and the loops
+// over the queue's 64-entry chunks run to the live length instead of being unrolled CAPC times.
+template <bool BIG>
+__device__ __forceinline__ void queue_sync() {
+  if constexpr (BIG) __threadfence();
+  __syncthreads();
+}
+
+template <int CAPC, class Dist, bool INSTR = false, bool BIG = false>
 __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   extern __shared__ uint32_t smem[];
   constexpr int CAP = CAPC * 64;
@@ -68,6 +78,10 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   float *Cd = (float *)(smem + CAP);       //
   uint32_t *Qid = smem + 2 * CAP;          // layer queue: NodeIds | EXPF (lib.rs:264)
   float *Qd = (float *)(smem + 3 * CAP);   //
+  if constexpr (BIG) {
+    Qid = a.big_q + (uint64_t)blockIdx.x * 2u * a.cap_max;
+    Qd = (float *)(Qid + a.cap_max);
+  }
   uint32_t *S = smem + 4 * CAP;            // prefix scratch [CAP + 64]
   float *dist_lds = (float *)(smem + 5 * CAP + 64);  // DistPQ: the query's lookup table
   if (Dist::GLOBAL_TABLE) dist_lds = (float *)((char *)a.pq_tables + (size_t)blockIdx.x * a.pq_table_bytes);
@@ -136,7 +150,8 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     // candidates parked in the output rows in between
     const uint32_t layer_hi = a.layer_hi ? a.layer_hi : a.n_layers;
     if (layer_lo && a.status[q] != ST_OK) continue;  // failed in the first launch: keep its status
-    const uint32_t qnode = a.first_node + q;  // knn modes: the query is a node of the bottom layer
+    // knn modes: the query is a node of the bottom layer
+    const uint32_t qnode = (BIG && a.knn_nodes) ? a.knn_nodes[q] : a.first_node + q;
     uint32_t qvec = a.knn_mode ? a.layers[last_layer].nodes[qnode] : (a.qids ? a.qids[q] : 0u);
     // row of this query in the dense table: its launch position, or (the build's kept table) its NodeId in layer X
     uint64_t trow = qpos;
@@ -153,6 +168,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     uint32_t n_dist0 = 0, n_hops0 = 0;  // counters a split descent brought in from its earlier launches
     uint32_t clen = 0;
     uint32_t ef = a.ef;  // queue capacity; grows in threshold_nn mode (resize_capacity)
+    bool big_written = false;
 
     if (layer_lo) {
       clen = a.out_len[q];
@@ -195,7 +211,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         for (uint32_t i = lane; i < a.tiny_n; i += 64) Dl[i] = Dg[i];
       for (uint32_t i = lane; i < tiny_words; i += 64) Vl[i] = 0u;
     }
-    __syncthreads();
+    queue_sync<BIG>();
 
     for (uint32_t li = a.knn_mode ? last_layer : layer_lo; li < layer_hi && err == ST_OK; li++) {
       PhLayerDev L = a.layers[li];
@@ -253,7 +269,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
         qlen = clen;
       }
-      __syncthreads();
+      queue_sync<BIG>();
 
       // Hnsw::threshold_nn (lib.rs:930-962, knn_mode == 2) calls closest_nodes repeatedly on a
       // growing queue; everything else runs this block once
@@ -266,7 +282,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         if (thr_last_size > 1 || n_hops > 0) {
           // a fresh closest_nodes call: every queue entry is a seed again (lib.rs:182-187)
 #pragma unroll
-          for (int c = 0; c < CAPC; c++) {
+          for (int c = 0; c < (BIG ? (int)((qlen + 63u) >> 6) : CAPC); c++) {
             uint32_t i = lane + 64u * c;
             if (i < qlen) {
               uint32_t nid = Qid[i] & IDM;
@@ -274,7 +290,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               atomicOr(&vis[nid >> 5], 1u << (nid & 31));
             }
           }
-          __syncthreads();
+          queue_sync<BIG>();
         }
       }
       // ---- closest_nodes  lib.rs:175-248
@@ -285,7 +301,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
 #pragma unroll
         for (int c = 0; c < CAPC; c++)
           if (lane + 64u * c < qlen) Qs[lane + 64u * c] = 0u;  // seeds: NodeDistance::ZERO  lib.rs:182-185
-        __syncthreads();
+        queue_sync<BIG>();
       }
       // every queue entry below scan_from has been expanded: the pop scan starts at its 64-entry chunk,
       // and a hop's merge touches only the chunks from its first insertion point on
@@ -317,6 +333,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
         if (pop >= 0) {
           if (lane == 0) Qid[pop] = cur | EXPF;
+          if constexpr (BIG) __threadfence();  // the merge below reads the slot back from another lane
         } else {
           if (ovf_n == 0) break;
           wait_vm0();  // spill stores of this wave have reached L2
@@ -497,6 +514,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // both chunks are in registers before either is overwritten
+            if constexpr (BIG) wait_vm0();
             const uint32_t np1 = i1 + sh1, np0 = i0 + sh0;
             if (has1 && np1 < ef) {
               Qid[np1] = qi1;
@@ -538,7 +556,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           if (ins) newpos = pos + rank;
           pos_min = rl32(pos, __builtin_ctzll(__ballot(ins && rank == 0u)));  // the smallest entering key's
           PH_TICK(5)
-          __syncthreads();
+          queue_sync<BIG>();
           PH_TICK(6)
         }
         {
@@ -561,7 +579,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
         qlen = min(ef, qlen + m);
         scan_from = min(pop >= 0 ? (uint32_t)pop + 1u : scan_from, pos_min);
-        __syncthreads();
+        queue_sync<BIG>();
         PH_TICK(4)
         if (ovf_n > ovf_cap) {
           err = ST_OVERFLOW;
@@ -592,7 +610,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         for (uint32_t i = lane; i < tiny_words; i += 64) Vl[i] = 0u;
       } else {
 #pragma unroll
-        for (int c = 0; c < CAPC; c++) {
+        for (int c = 0; c < (BIG ? (int)((qlen + 63u) >> 6) : CAPC); c++) {
           uint32_t i = lane + 64u * c;
           if (i < qlen) vis[(Qid[i] & IDM) >> 5] = 0u;
         }
@@ -608,7 +626,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       if (a.knn_mode != 2) break;
       thr_last = Qd[qlen - 1];  // pq.last().1  lib.rs:948
       if (thr_last < a.threshold && qlen == ef) {  // pq.resize_capacity(capacity * 2)  lib.rs:949-951
-        if (ef * 2 > (uint32_t)CAP) {
+        if (ef * 2 > (BIG ? a.cap_max : (uint32_t)CAP)) {
           err = ST_CAPACITY;
           break;
         }
@@ -617,6 +635,34 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
       }  // closest_nodes call loop
       if (err != ST_OK) break;
 
+      if constexpr (BIG) {
+        // the knn modes start from no running candidates, so closest_vectors' tail (lib.rs:268-276) followed by
+        // candidates.merge_pairs (search.rs:136) is the queue itself: it goes straight to the output row, of which
+        // the caller reads out_stride entries at most
+        const uint32_t os = a.out_stride ? a.out_stride : a.ef;
+        uint32_t kept = 0;
+        for (uint32_t base = 0; base < qlen && kept < os; base += 64) {
+          const uint32_t i = base + lane;
+          const bool has = i < qlen;
+          const uint32_t nid = has ? (Qid[i] & IDM) : 0u;
+          const uint32_t v = has ? (identity ? nid : L.nodes[nid]) : PH_EMPTY32;
+          const bool keep = has && v != excl;
+          const uint64_t km = __ballot(keep);
+          const uint32_t at = kept + __popcll(km & lt);
+          if (keep && at < os) {
+            a.out_ids[(uint64_t)q * os + at] = v;
+            a.out_d[(uint64_t)q * os + at] = Qd[i];
+          }
+          kept += __popcll(km);
+        }
+        clen = min(kept, os);
+        for (uint32_t i = clen + lane; i < os; i += 64) {
+          a.out_ids[(uint64_t)q * os + i] = PH_EMPTY32;
+          a.out_d[(uint64_t)q * os + i] = PH_FMAX;
+        }
+        big_written = true;
+        continue;
+      }
       // ---- closest_vectors tail: NodeId -> VectorId, filter(include), take(count)  lib.rs:268-276
       const uint32_t candidate_count = (a.n_layers == 1 || li == last_layer) ? ef : a.upper;  // search.rs:122-126
       uint32_t bv[CAPC];
@@ -637,7 +683,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         kept += __popcll(km);
       }
       const uint32_t blen = min(kept, candidate_count);
-      __syncthreads();
+      queue_sync<BIG>();
 #pragma unroll
       for (int c = 0; c < CAPC; c++) {
         if (bpos[c] != PH_EMPTY32) {
@@ -645,7 +691,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           Qd[bpos[c]] = bd[c];
         }
       }
-      __syncthreads();
+      queue_sync<BIG>();
 
       // ---- candidates.merge_pairs(&closest)  search.rs:136 : sorted set union, cap ef.
       // An element present in both lists (same id => same distance) is kept once.
@@ -673,7 +719,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         dups += __popcll(dm);
       }
       if (lane == 0) S[CAP] = dups;
-      __syncthreads();
+      queue_sync<BIG>();
 #pragma unroll
       for (int c = 0; c < CAPC; c++) {
         uint32_t j = lane + 64u * c;
@@ -688,7 +734,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
           bpos[c] = j + (la - dupb);
         }
       }
-      __syncthreads();
+      queue_sync<BIG>();
 #pragma unroll
       for (int c = 0; c < CAPC; c++) {
         if (cpos[c] < ef) {
@@ -701,7 +747,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         }
       }
       clen = min(ef, clen - dups + blen);
-      __syncthreads();
+      queue_sync<BIG>();
     }
 
     if (err != ST_OK) {
@@ -713,7 +759,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
     }
     // (candidates.iter().collect(), ..)  search.rs:139
     const uint32_t ostride = a.out_stride ? a.out_stride : a.ef;
-    for (uint32_t i = lane; i < ostride; i += 64) {
+    for (uint32_t i = lane; i < ostride && !big_written; i += 64) {
       a.out_ids[(uint64_t)q * ostride + i] = i < clen ? Cid[i] : PH_EMPTY32;
       a.out_d[(uint64_t)q * ostride + i] = i < clen ? Cd[i] : PH_FMAX;
     }
@@ -769,7 +815,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
         a.out_stats[2 * (uint64_t)q + 1] = n_hops;
       }
     }
-    __syncthreads();
+    queue_sync<BIG>();
   }
 }
 
@@ -798,6 +844,12 @@ __global__ __launch_bounds__(64, 1) void ph_search_kernel_lat(PhSearchArgs a) {
 template <int CAPC, int NV>
 __global__ __launch_bounds__(64) void ph_search_kernel_instr(PhSearchArgs a) {
   ph_search_body<CAPC, DistF32<NV>, true>(a);
+}
+
+// Hnsw::threshold_nn past the LDS queues: the BIG body (queue in global memory, capacity a.cap_max)
+template <class Dist>
+__global__ __launch_bounds__(64) void ph_search_kernel_big(PhSearchArgs a) {
+  ph_search_body<2, Dist, false, true>(a);
 }
 
 // the register-table policy keeps a whole lookup table in VGPRs: two waves per SIMD is its register budget
@@ -1039,6 +1091,39 @@ static int search_launch_dense(PhWorkspace &ws, PhSearchArgs &a, hipStream_t str
   a.counter = ws.counter;
   PH_HIP(hipMemsetAsync(ws.counter, 0, 512, stream));
   a.seg = a.order ? (a.nq + 7u) / 8u : 0u;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a);
+  PH_HIP(hipGetLastError());
+  return 0;
+}
+
+int ph_search_launch_big(const phnsw_index *ix, PhSearchArgs &a, uint32_t grid, hipStream_t stream) {
+  const phnsw_store *s = ix->store;
+  const bool pq = s->codes != nullptr;
+  const int nv = pq ? 0 : pick_nv(a.dist.nv4);
+  ph_search_fn fn = nullptr;
+  size_t pq_lds = 0;
+  if (s->codes16) {
+    fn = nv == 1 ? (ph_search_fn)ph_search_kernel_big<DistPQS<1>>
+                 : (nv == 3 ? (ph_search_fn)ph_search_kernel_big<DistPQS<3>> : (nv == 6 ? (ph_search_fn)ph_search_kernel_big<DistPQS<6>> : nullptr));
+  } else if (pq) {
+    fn = (ph_search_fn)ph_search_kernel_big<DistPQ>;  // the per-query table in LDS
+    pq_lds = ph_pq_lds_bytes(s);
+  } else {
+    fn = nv == 1 ? (ph_search_fn)ph_search_kernel_big<DistF32<1>>
+                 : (nv == 3 ? (ph_search_fn)ph_search_kernel_big<DistF32<3>> : (nv == 6 ? (ph_search_fn)ph_search_kernel_big<DistF32<6>> : nullptr));
+  }
+  const size_t lds = lds_bytes(2, pq_lds);
+  if (!fn || lds > 160 * 1024 || a.knn_mode != 2 || !a.big_q || a.cap_max < 2 * a.ef || grid == 0) {
+    ph_set_error("unsupported search shape: threshold_nn with a queue of %u entries, dim %u", a.cap_max, s->dim);
+    return PHNSW_E_UNSUPPORTED;
+  }
+  if (lds > 64 * 1024)
+    PH_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  a.pq_tables = nullptr;
+  a.pq_table_bytes = 0;
+  a.seg = 0;
+  a.order = nullptr;
+  PH_HIP(hipMemsetAsync(a.counter, 0, 512, stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a);
   PH_HIP(hipGetLastError());
   return 0;

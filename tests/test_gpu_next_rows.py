@@ -56,6 +56,42 @@ def test_knn_and_threshold_nn_parity_large():
         assert [np.float32(x[1]).view(np.uint32) for x in got] == [x.view(np.uint32) for x in td[i, :int(tl[i])]]
 
 
+def _same_threshold_rows(res, ti, td, tl):
+    for i, (v, got) in enumerate(res):
+        assert [x[0] for x in got] == [int(x) for x in ti[i, :int(tl[i])]], i
+        assert [np.float32(x[1]).view(np.uint32) for x in got] == [x.view(np.uint32) for x in td[i, :int(tl[i])]], i
+
+
+def test_threshold_nn_queue_grows_past_lds(monkeypatch):
+    """resize_capacity without a bound (lib.rs:949-951): a radius that a third of the layer falls in makes the queue
+    double to 2048 and 4096 entries -- past the 1024 the LDS queues hold, through the global-memory queues of
+    ph_search_kernel_big -- and every row still equals the oracle's, whose queue is realloc'd without limit"""
+    n, dim = 12000, 16
+    rows = oracle.synth_rows(0, n, dim)
+    oix = oracle.Index.generate(rows, np.arange(n), oracle.default_build_params(seed=5), dim=dim,
+                                sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim])
+    g = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)])
+    d0 = (1.0 - rows[:, :dim] @ rows[0, :dim]) / 2
+    thr = np.float32(np.quantile(d0, 0.3))
+    ti, td, tl = oix.threshold_nn(thr, 2, 16, max_out=n)
+    assert int(tl.max()) > 2048 and int(tl.min()) < 1024       # both paths are needed, and two doublings past LDS
+    res = g.threshold_nn(float(thr), 2, 16, max_out=n)
+    _same_threshold_rows(res, ti, td, tl)
+    # an initial depth the LDS queues cannot hold at all
+    ti, td, tl = oix.threshold_nn(thr, 2, 1500, max_out=n)
+    _same_threshold_rows(g.threshold_nn(float(thr), 2, 1500, max_out=n), ti, td, tl)
+    # the global-memory queues alone, also where the LDS queues would have done
+    monkeypatch.setenv("PHNSW_THRESHOLD_ALL_BIG", "1")
+    thr2 = np.float32(np.quantile(d0, 0.01))
+    ti, td, tl = oix.threshold_nn(thr2, 2, 4, max_out=512)
+    assert 8 < int(tl.max()) < 512
+    _same_threshold_rows(g.threshold_nn(float(thr2), 2, 4, max_out=512), ti, td, tl)
+    # few resident waves (the memory budget of the big queues): every wave serves many nodes in turn
+    monkeypatch.setenv("PHNSW_THRESHOLD_BIG_BYTES", "400000")
+    _same_threshold_rows(g.threshold_nn(float(thr2), 2, 4, max_out=512), ti, td, tl)
+
+
 def test_serialize_layout_and_roundtrip(tmp_path):
     """serialize_hnsw / deserialize_hnsw  serialize.rs:33-209"""
     n, dim = 1500, 16
