@@ -430,6 +430,32 @@ def worker(args):
                 ms = run.isolated_ms(sp, b, reps=5)
                 batch_sweep.append({"queries": b, "kernel_ms": round(ms, 3), "queries_per_s": round(b / ms * 1e3)})
             log("batch sweep: " + ", ".join("%d: %.2f ms" % (x["queries"], x["kernel_ms"]) for x in batch_sweep))
+        # ---- the same steps with TWO batches in flight (two query batches, two streams, alternating): the head of a
+        # launch (matrix-core table pass, phase-locked start) runs under the tail of the one before.  A secondary cell:
+        # the headline stays K steps on one stream.
+        two = None
+        if rank == 0 and world == 1:
+            q2 = make_store(ph, kind, args.nq, args.dim, 2 ** 33, local)
+            r2 = Runner(index, q2, ef_max=ef)
+            gt2 = ground_truth(store, q2)
+            ref_ids = run.result_ids(ef).clone()
+            s2 = torch.cuda.Stream(device=dev)
+            lanes = [(run, stream), (r2, s2.cuda_stream)]
+            for i in range(4):
+                lanes[i & 1][0].launch(sp, on_stream=lanes[i & 1][1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                lanes[i & 1][0].launch(sp, on_stream=lanes[i & 1][1])
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            assert int(r2.status.abs().sum()) == 0 and bool((run.result_ids(ef) == ref_ids).all())
+            two = {"ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_s": round(args.nq * args.steps / el2),
+                   "recall_at_10_second_batch": round(recall_at_10(r2.result_ids(ef), gt2), 4),
+                   "how": "the same %d-query steps, two query batches alternating over two streams (each batch's steps in "
+                          "order on its own stream); results of the first batch identical to the one-stream run" % args.nq}
+            log("two batches in flight: %.3f ms per step = %.0f q/s" % (two["ms_per_step"], two["queries_per_s"]))
+            del r2, q2, gt2, ref_ids
         # ---- a 100 000-query batch of the same workload (round 1's step size): throughput form
         big = None
         if rank == 0 and world == 1 and args.nq < 100_000 and not args.ef:
@@ -453,7 +479,7 @@ def worker(args):
                    elapsed=elapsed, kernel_ms=float(np.mean(kms)), alg_bytes=alg_bytes, gathered_bytes=gathered_bytes,
                    n_table=n_table, search_ms=search_ms, table_ms=table_ms, n_dist_per_query=n_dist / args.nq,
                    n_hops_per_query=n_hops / args.nq, sweep=sweep, batch_sweep=batch_sweep, dispatches=dispatches,
-                   batch_100k=big,
+                   batch_100k=big, two_in_flight=two,
                    build_roofline={"bound": "hbm", "distance_evals": binfo["build_distance_evals"], "hops": binfo["build_hops"],
                                    "evals_equivalent_bytes": build_bytes,
                                    "evals_equivalent_gbs": round(build_bytes / binfo["build_s"] / 1e9, 1),
@@ -602,6 +628,7 @@ def worker(args):
             "sharded_build_model": sharded_model,
             "batch_sweep": res["batch_sweep"],
             "batch_100k": res["batch_100k"],
+            "two_batches_in_flight": res["two_in_flight"],
             "build_roofline": res["build_roofline"],
             "build_self_recall": res["build_self_recall"],
             "sweep": res["sweep"],
