@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--skip-iid", dest="no_iid", action="store_true", help="skip the iid-uniform cells")
     ap.add_argument("--skip-tight", dest="no_tight", action="store_true", help="skip round 1's dataset / batch cells")
     ap.add_argument("--skip-pq", dest="no_pq", action="store_true", help="skip the BASELINE config-5 (PQ) measurement")
+    ap.add_argument("--single-build", action="store_true", help="build the headline index once instead of twice")
     ap.add_argument("--no-pmc", action="store_true", help="driver: skip the rocprofv3 counter passes")
     ap.add_argument("--skip-sharded-build", dest="no_sharded_build", action="store_true",
                     help="N > 1: do not measure the sharded index build after the search measurement")
@@ -213,11 +214,25 @@ def worker(args):
         build_s = time.time() - t0
         if world > 1:
             dist.barrier()
+        runs = [round(build_s, 3)]
+        if world == 1 and kind == "survey" and not args.single_build:
+            # the same build once more (deterministic: the same graph): a box's first build has come out up to 25 %
+            # slower than its second; both times are printed, the figure is the faster one
+            first = index._layer(index.layer_count() - 1).neighbors.copy()
+            del index
+            torch.cuda.synchronize()
+            t0 = time.time()
+            index = ph.Hnsw.generate(store, np.arange(store.n, dtype=np.uint64), bp)
+            torch.cuda.synchronize()
+            runs.append(round(time.time() - t0, 3))
+            assert np.array_equal(first, index._layer(index.layer_count() - 1).neighbors), "two builds of one store differ"
+            del first
+            build_s = min(build_s, runs[-1])
         mode = "single GPU" if world == 1 else "every rank built the full index (search replicas); sharded build: see sharded_build"
         b_dist, b_hops = index.counters()  # every search of the build rounds
         layers = [index._layer(l).node_count() for l in range(index.layer_count())]
         log("%s: index built in %.1f s (%.0f vectors/s), layers %s" % (kind, build_s, store.n / build_s, layers))
-        info = {"build_s": build_s, "build_mode": mode, "layers": layers,
+        info = {"build_s": build_s, "build_runs_s": runs, "build_mode": mode, "layers": layers,
                 "build_self_recall": round(index.stochastic_recall(), 5),  # the reference's own estimator, lib.rs:1463-1499
                 "build_distance_evals": b_dist, "build_hops": b_hops}
         return index, info
@@ -584,6 +599,7 @@ def worker(args):
             "recall_target_met": res["recall_target_met"],
             "build_vectors_per_sec": round(args.n / res["build_s"], 1),
             "build_mode": res["build_mode"],
+            "build_runs_s": res["build_runs_s"],
             "all_gather": res.get("all_gather"),
             "layers": res["layers"],
             "queries_per_step_per_gpu": args.nq, "argv": " ".join(sys.argv[1:]),
