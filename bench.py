@@ -874,7 +874,7 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
                             "limiter": "not memory: the per-hop dependency chain at 2 waves per SIMD (the query's 96-row 8-bit table "
                                        "occupies 96 of a wave's 256 registers) -- neighbour row, visited test-and-set beside the "
                                        "code rows, 96 ds_bpermute look-ups (one crossbar pass serves one table row whatever the "
-                                       "number of candidates), queue merge; counters in profiles/r03/pq_kernel_summary.json",
+                                       "number of candidates), queue merge; counters in profiles/r03/pq_counters.txt",
                             "algorithmic_definition": "evaluations x m code bytes + hops x W x 4 B + re-ranked rows x row bytes"},
                "vs_f32_note": "PQ trades 32x less vector memory (96 B instead of 3 072 B per vector) for ~1.4x the hops at equal "
                               "recall; on this part a wave streams a 3 KB row faster than 96 dependent table look-ups issue"}

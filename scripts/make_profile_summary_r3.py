@@ -36,15 +36,30 @@ if cur:
 nq = trace["queries_per_step_per_gpu"]
 head = [L for L in launches if len(L) in (3, 5) and "ph_search_kernel" in L[-1]["Kernel_Name"]]
 # the timed steps + isolated launches of the headline share one shape; take the `isolated` ones that follow the timed region
-steps = trace["steps"] + trace["warmup"]
+steps = trace["steps"]
 sel = head[-(isolated + 200):]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 by_grid = {}
 for L in head:
     by_grid.setdefault(L[-1].get("Grid_Size", L[-1].get("Grid_Size_X", "")), []).append(L)
-main = max(by_grid.values(), key=len)  # the headline shape is the most frequent one (sweep cells use 8192 queries)
-main = [L for L in main if abs(dur(L[-1]) - sorted(dur(x[-1]) for x in main)[len(main) // 2]) / dur(L[-1]) < 0.25]
-last = main[-isolated:]
+main = max(by_grid.values(), key=len)  # the headline shape is the most frequent one
+# the timed region is the first run of >= `steps` launches issued back to back (the next launch's first kernel starts
+# within 60 us of the previous search kernel's end, and not before it -- the two-batches-in-flight cell overlaps --;
+# the sweep's isolated cells are 100-200 us apart);
+# the isolated launches (one per HIP-event reading, host synchronisation in between) are the `isolated` that follow
+gap = lambda a, b: (int(b[0]["Start_Timestamp"]) - int(a[-1]["End_Timestamp"])) / 1e3  # us
+run_start, run_len, timed_end = 0, 1, None
+for i in range(1, len(main)):
+    if 0 <= gap(main[i - 1], main[i]) < 60:
+        run_len += 1
+    else:
+        if run_len >= steps:
+            timed_end = i
+            break
+        run_start, run_len = i, 1
+if timed_end is None:
+    raise SystemExit("no timed region of %d back-to-back launches in the trace" % steps)
+last = main[timed_end:timed_end + isolated]
 
 
 def short(r):
