@@ -1030,21 +1030,28 @@ struct GrowBuf {
 // threshold_nn for the nodes whose queue outgrew LDS: the same search from the start with the queue in global memory
 // (ph_search_kernel_big), its capacity doubled from launch to launch until nobody asks for more.  A queue never
 // holds more than the layer's nodes, so a capacity of twice that is final.
-static int threshold_nn_big(const phnsw_index *ix, const phnsw_search_params *sp, float threshold, std::vector<uint32_t> nodes,
-                            const std::vector<uint32_t> &h_nodes, uint64_t max_out, uint64_t *out_ids, float *out_d,
-                            uint64_t *out_len) {
+static int threshold_nn_big(const phnsw_index *ix, const phnsw_search_params *sp, float threshold,
+                            const std::vector<uint32_t> &all_nodes, const std::vector<uint32_t> &h_nodes, uint64_t max_out,
+                            uint64_t *out_ids, float *out_d, uint64_t *out_len) {
   const PhLayerHost &L = ix->layers.back();
   const uint32_t n = L.n_nodes;
   const uint64_t isd = sp->number_of_candidates;
   const uint32_t os = (uint32_t)std::min<uint64_t>(max_out + 2, (uint64_t)n + 1);  // self + max_out + one more to tell "too many"
   const uint64_t words = ((uint64_t)n + 31) / 32 + 1;
-  uint64_t cap = isd * 2;  // capacities follow the queue's own doubling sequence
-  while (cap <= 1024) cap *= 2;
+  uint64_t cap0 = isd * 2;  // capacities follow the queue's own doubling sequence
+  while (cap0 <= 1024) cap0 *= 2;
   GrowBuf<uint32_t> d_nodes, d_vis, d_q, d_oid, d_len, d_status, d_counter;
   GrowBuf<float> d_od;
   GrowBuf<uint2> d_ovf;
   std::vector<uint32_t> h_ids, h_len, h_status;
   std::vector<float> h_d;
+  // the output rows of a launch are [nodes][os]: the list goes through in pieces that keep them below 1 GiB
+  size_t piece = std::max<size_t>(1, std::min<size_t>(16384, (1ull << 30) / ((size_t)os * 8)));
+  if (const char *e = getenv("PHNSW_THRESHOLD_BIG_PIECE"))  // tests
+    if (atoll(e) > 0) piece = (size_t)atoll(e);
+  for (size_t c0 = 0; c0 < all_nodes.size(); c0 += piece) {
+  std::vector<uint32_t> nodes(all_nodes.begin() + c0, all_nodes.begin() + std::min(all_nodes.size(), c0 + piece));
+  uint64_t cap = cap0;
   while (!nodes.empty()) {
     if (cap > 0x7FFFFFFFull) {
       ph_set_error("threshold_nn: queue capacity beyond 2^31");
@@ -1132,6 +1139,7 @@ static int threshold_nn_big(const phnsw_index *ix, const phnsw_search_params *sp
     nodes.swap(again);
     cap *= 2;
   }
+  }
   return 0;
 }
 
@@ -1158,7 +1166,7 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (initial_search_depth > CAPMAX || getenv("PHNSW_THRESHOLD_ALL_BIG")) {
     big.resize(n);
     for (uint32_t i = 0; i < n; i++) big[i] = i;
-    return threshold_nn_big(ix, &sp, threshold, std::move(big), h_nodes, max_out, out_ids, out_d, out_len);
+    return threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len);
   }
   uint32_t *oid = nullptr, *olen = nullptr, *ostat = nullptr;
   float *od = nullptr;
@@ -1222,6 +1230,6 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (od) hipFree(od);
   if (olen) hipFree(olen);
   if (ostat) hipFree(ostat);
-  if (!rc && !big.empty()) rc = threshold_nn_big(ix, &sp, threshold, std::move(big), h_nodes, max_out, out_ids, out_d, out_len);
+  if (!rc && !big.empty()) rc = threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len);
   return rc;
 } catch (...) { return ph_caught(); }

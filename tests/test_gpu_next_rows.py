@@ -89,6 +89,7 @@ def test_threshold_nn_queue_grows_past_lds(monkeypatch):
     _same_threshold_rows(g.threshold_nn(float(thr2), 2, 4, max_out=512), ti, td, tl)
     # few resident waves (the memory budget of the big queues): every wave serves many nodes in turn
     monkeypatch.setenv("PHNSW_THRESHOLD_BIG_BYTES", "400000")
+    monkeypatch.setenv("PHNSW_THRESHOLD_BIG_PIECE", "5000")   # and the node list in three pieces
     _same_threshold_rows(g.threshold_nn(float(thr2), 2, 4, max_out=512), ti, td, tl)
 
 
