@@ -625,6 +625,11 @@ uint32_t ph_default_ovf_cap(uint32_t ef) {
 }
 static uint32_t default_ovf_cap(uint32_t ef) { return ph_default_ovf_cap(ef); }
 
+// batches at least this large descend in several launches (PHNSW_TWO_LAUNCH_MIN overrides: tuning knob)
+static uint64_t two_launch_min() {
+  const char *e = getenv("PHNSW_TWO_LAUNCH_MIN");
+  return (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (uint64_t)PH_TWO_LAUNCH_MIN;
+}
 static std::atomic<uint64_t> g_two_launch_count{0};  // tests check that the split path really ran
 extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_count.load(); }
 // chunks of the last descent on this index (phnsw_last_search_dispatches then describes the last one)
@@ -695,7 +700,7 @@ int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t l
   // (not for PQ stores: their searches are not bound by where rows come from, and every launch
   // would build the per-query table again)
   const bool split = ix->store->rows && !a.order && !knn_mode && !out_stride && !out_index && first_big < a.n_layers &&
-                     nq >= PH_TWO_LAUNCH_MIN &&
+                     nq >= two_launch_min() &&
                      !getenv("PHNSW_NO_LOCALITY");
   if (split) {
     g_two_launch_count++;

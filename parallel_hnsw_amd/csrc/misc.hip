@@ -1,7 +1,11 @@
 // Small gfx950 kernels around the search: K1 distance batch (Comparator::compare_vec
 // batched, /root/reference/src/lib.rs:69-73), synthetic data (bigvec.rs:59-65
 // distribution), id-map scatter, NaN scan.
+#define PH_RAW_ALLOC  // this file holds the accounted wrappers themselves
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
 
 #include "phnsw_device.h"
 
@@ -199,6 +203,31 @@ size_t pool_class(size_t bytes) {
 }
 }  // namespace
 
+// Device allocation is host work (page tables): its wall time is accounted so that a slow build can be told from a
+// slow allocator (phnsw_debug_alloc_stats; bench.py prints it next to the build time).
+static std::atomic<uint64_t> g_alloc_ns{0}, g_alloc_calls{0}, g_alloc_bytes{0};
+hipError_t ph_timed_malloc(void **p, size_t bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  hipError_t e = hipMalloc(p, bytes);
+  g_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  g_alloc_calls++;
+  if (e == hipSuccess) g_alloc_bytes += bytes;
+  return e;
+}
+hipError_t ph_timed_free(void *p) {
+  const auto t0 = std::chrono::steady_clock::now();
+  hipError_t e = hipFree(p);
+  g_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  g_alloc_calls++;
+  return e;
+}
+// out[0] = nanoseconds inside hipMalloc / hipFree, out[1] = calls, out[2] = bytes allocated -- since the last call
+extern "C" void phnsw_debug_alloc_stats(uint64_t *out) {
+  out[0] = g_alloc_ns.exchange(0);
+  out[1] = g_alloc_calls.exchange(0);
+  out[2] = g_alloc_bytes.exchange(0);
+}
+
 hipError_t ph_pool_alloc(void **p, size_t bytes) {
   int dev = 0;
   hipGetDevice(&dev);
@@ -215,10 +244,10 @@ hipError_t ph_pool_alloc(void **p, size_t bytes) {
     }
   }
   const size_t cb = c & ((1ull << 56) - 1);
-  hipError_t e = hipMalloc(p, cb);
+  hipError_t e = ph_timed_malloc(p, cb);
   if (e != hipSuccess) {  // memory held by the cache may be what is missing
     ph_pool_trim();
-    e = hipMalloc(p, cb);
+    e = ph_timed_malloc(p, cb);
   }
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> g(g_pool_mutex);
@@ -232,12 +261,12 @@ void ph_pool_free(void *p) {
   std::lock_guard<std::mutex> g(g_pool_mutex);
   auto it = g_pool_size.find(p);
   if (it == g_pool_size.end()) {
-    hipFree(p);
+    ph_timed_free(p);
     return;
   }
   if (g_pool_cached + cb0(it->second) > POOL_CACHE_LIMIT) {
     g_pool_size.erase(it);
-    hipFree(p);
+    ph_timed_free(p);
     return;
   }
   g_pool_free.emplace(it->second, p);
@@ -248,7 +277,7 @@ void ph_pool_trim(void) {
   std::lock_guard<std::mutex> g(g_pool_mutex);
   for (auto &kv : g_pool_free) {
     g_pool_size.erase(kv.second);
-    hipFree(kv.second);
+    ph_timed_free(kv.second);
   }
   g_pool_free.clear();
   g_pool_cached = 0;

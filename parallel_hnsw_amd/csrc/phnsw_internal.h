@@ -262,6 +262,12 @@ uint32_t ph_default_ovf_cap(uint32_t ef);
 // scratch allocator of the build path (misc.hip): hipMalloc / hipFree cost ~0.1 ms and a device
 // sync each, a build issues thousands of them; freed blocks are kept by size class and handed
 // out again (everything on the path runs on the null stream, so reuse is stream ordered)
+hipError_t ph_timed_malloc(void **p, size_t bytes);  // hipMalloc / hipFree with their wall time accounted (misc.hip)
+hipError_t ph_timed_free(void *p);
+#ifndef PH_RAW_ALLOC  // every device allocation of the library goes through the accounted forms
+#define hipMalloc(p, n) ph_timed_malloc((void **)(p), (n))
+#define hipFree(p) ph_timed_free((void *)(p))
+#endif
 hipError_t ph_pool_alloc(void **p, size_t bytes);
 void ph_pool_free(void *p);
 void ph_pool_trim(void);  // give everything cached back to the driver

@@ -450,10 +450,10 @@ size_t ph_tiny_lds_bytes(const PhSearchArgs &a) {
 template <class T>
 static hipError_t grow(T **p, size_t *have, size_t need) {
   if (*have >= need) return hipSuccess;
-  if (*p) hipFree(*p);
+  if (*p) ph_timed_free(*p);
   *p = nullptr;
   *have = 0;
-  hipError_t e = hipMalloc((void **)p, need);
+  hipError_t e = ph_timed_malloc((void **)p, need);
   if (e == hipSuccess) *have = need;
   return e;
 }
@@ -613,11 +613,11 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
 
 void ph_build_table_free(phnsw_index *ix) {
   for (PhBuildTable &b : ix->bt)
-    if (b.D) hipFree(b.D);
+    if (b.D) ph_timed_free(b.D);
   ix->bt.clear();
 }
 static void build_table_drop(PhBuildTable &b) {  // the rows go, the slot (which layer it belongs to) stays
-  if (b.D) hipFree(b.D);
+  if (b.D) ph_timed_free(b.D);
   b.D = nullptr;
   b.bytes = 0;
   b.lo = b.hi = b.lo_alloc = b.hi_alloc = 0;
@@ -667,7 +667,7 @@ int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, co
     size_t mfree = 0, mtotal = 0;
     PH_HIP(hipMemGetInfo(&mfree, &mtotal));
     if (bytes + (8ull << 30) > mfree || bytes > mtotal / 2) return 0;  // the searches' own workspaces come first
-    if (hipMalloc(&B.D, bytes) != hipSuccess) {
+    if (ph_timed_malloc((void **)&B.D, bytes) != hipSuccess) {
       (void)hipGetLastError();
       B.D = nullptr;
       return 0;
