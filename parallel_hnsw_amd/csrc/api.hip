@@ -1037,14 +1037,14 @@ struct GrowBuf {
 // holds more than the layer's nodes, so a capacity of twice that is final.
 static int threshold_nn_big(const phnsw_index *ix, const phnsw_search_params *sp, float threshold,
                             const std::vector<uint32_t> &all_nodes, const std::vector<uint32_t> &h_nodes, uint64_t max_out,
-                            uint64_t *out_ids, float *out_d, uint64_t *out_len) {
+                            uint64_t *out_ids, float *out_d, uint64_t *out_len, uint32_t lds_cap) {
   const PhLayerHost &L = ix->layers.back();
   const uint32_t n = L.n_nodes;
   const uint64_t isd = sp->number_of_candidates;
   const uint32_t os = (uint32_t)std::min<uint64_t>(max_out + 2, (uint64_t)n + 1);  // self + max_out + one more to tell "too many"
   const uint64_t words = ((uint64_t)n + 31) / 32 + 1;
   uint64_t cap0 = isd * 2;  // capacities follow the queue's own doubling sequence
-  while (cap0 <= 1024) cap0 *= 2;
+  while (cap0 <= lds_cap) cap0 *= 2;  // what the LDS queues held has been tried
   GrowBuf<uint32_t> d_nodes, d_vis, d_q, d_oid, d_len, d_status, d_counter;
   GrowBuf<float> d_od;
   GrowBuf<uint2> d_ovf;
@@ -1163,7 +1163,8 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   const phnsw_store *s = ix->store;
   PH_HIP(hipSetDevice(s->device));
   const PhLayerHost &L = ix->layers.back();
-  const uint32_t n = L.n_nodes, CAPMAX = 1024, CHUNK = 16384;
+  // the LDS queues hold 1024 entries (512 over a shared-codebook store: its kernels come with queues of 128 and 512)
+  const uint32_t n = L.n_nodes, CAPMAX = s->codes16 ? 512 : 1024, CHUNK = 16384;
   phnsw_search_params sp = {initial_search_depth, initial_search_depth, probe_depth};
   std::vector<uint32_t> h_nodes(n);
   PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -1171,7 +1172,7 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (initial_search_depth > CAPMAX || getenv("PHNSW_THRESHOLD_ALL_BIG")) {
     big.resize(n);
     for (uint32_t i = 0; i < n; i++) big[i] = i;
-    return threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len);
+    return threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len, 0);
   }
   uint32_t *oid = nullptr, *olen = nullptr, *ostat = nullptr;
   float *od = nullptr;
@@ -1235,6 +1236,6 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   if (od) hipFree(od);
   if (olen) hipFree(olen);
   if (ostat) hipFree(ostat);
-  if (!rc && !big.empty()) rc = threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len);
+  if (!rc && !big.empty()) rc = threshold_nn_big(ix, &sp, threshold, big, h_nodes, max_out, out_ids, out_d, out_len, CAPMAX);
   return rc;
 } catch (...) { return ph_caught(); }

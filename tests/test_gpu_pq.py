@@ -323,6 +323,47 @@ def test_reference_shaped_quantizer():
     assert e.value.code == -7
 
 
+def _threshold_rows(res):
+    return [(v, [x[0] for x in got], [np.float32(x[1]).view(np.uint32) for x in got]) for v, got in res]
+
+
+def test_threshold_nn_over_codes_with_global_memory_queues(monkeypatch):
+    """threshold_nn (lib.rs:930-962) on both kinds of code stores: queues past the LDS limit go through
+    ph_search_kernel_big's DistPQ / DistPQS instances.  Per-sub-space codes: rows equal the oracle's; shared-codebook
+    u16 codes (no oracle form of this store): the global-memory queues alone give the rows the LDS queues give."""
+    n, dim, m, ksub = 8000, 16, 4, 64
+    rows, full, pq, ocodes, ocb = make(n, dim, m, ksub, seed=1)
+    bp_kw = dict(seed=2, promote=0)
+    oix = oracle.Index(rows, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    oix.set_pq(ocodes, ocb, table_f16=0)
+    obp = oracle.default_build_params(**bp_kw)
+    vs = oracle.shuffle(np.arange(n), obp.seed)
+    sizes = oracle.calculate_partitions(n, obp.order)
+    for i, sz in enumerate(sizes):
+        oix.generate_layer(vs[:sz], 48 if i == len(sizes) - 1 else 24, obp)
+        oix.improve_index(obp)
+    g = ph.Hnsw.from_layers(pq, [oix.layer(l) for l in range(oix.layer_count)])
+    thr = np.float32(np.quantile((1.0 - rows[:, :dim] @ rows[0, :dim]) / 2, 0.3))   # a third of the layer lies within it
+    ti, td, tl = oix.threshold_nn(thr, 2, 32, max_out=n)
+    assert int((tl > 1024).sum()) >= 20 and int(tl.min()) < 1024   # queues of 2 048 entries and more, and LDS ones
+    got = g.threshold_nn(float(thr), 2, 32, max_out=n)
+    for i, (v, ids_, bits) in enumerate(_threshold_rows(got)):
+        assert ids_ == [int(x) for x in ti[i, :int(tl[i])]], i
+        assert bits == [x.view(np.uint32) for x in td[i, :int(tl[i])]], i
+    # shared codebook, u16 codes
+    n2, dim2 = 3000, 64
+    rows2 = oracle.synth_rows(0, n2, dim2)
+    full2 = ph.VectorStore(rows2[:, :dim2], metric=ph.METRIC_L2)
+    qh = ph.QuantizedHnsw.reference_shaped(300, full2, 16, bp=ph.BuildParameters(seed=1), centroid_bp=ph.BuildParameters(seed=2),
+                                           quantized_search=ph.SearchParameters(64, 64, 2))
+    dq = qh.hnsw.search_batch(qids=np.arange(1), sp=ph.SearchParameters(512, 512, 2))[1][0]
+    thr2 = float(dq[40])
+    lds = _threshold_rows(qh.hnsw.threshold_nn(thr2, 2, 8, max_out=1024))
+    assert max(len(r[1]) for r in lds) > 16
+    monkeypatch.setenv("PHNSW_THRESHOLD_ALL_BIG", "1")
+    assert _threshold_rows(qh.hnsw.threshold_nn(thr2, 2, 8, max_out=1024)) == lds
+
+
 @pytest.mark.parametrize("world,rank", [(2, 1), (3, 0), (8, 7)])
 def test_sharded_encode_equals_single_gpu_encode(world, rank):
     """SURVEY 8e row 3 (pq.rs:326-333: the encode is one independent job per vector): both quantizers with the
