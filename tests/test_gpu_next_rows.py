@@ -93,6 +93,29 @@ def test_threshold_nn_queue_grows_past_lds(monkeypatch):
     _same_threshold_rows(g.threshold_nn(float(thr2), 2, 4, max_out=512), ti, td, tl)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_threshold_nn_random_shapes(seed, monkeypatch):
+    """random layers, radii, initial depths and probe depths: the LDS queues, the global-memory queues alone
+    (PHNSW_THRESHOLD_ALL_BIG) and the oracle agree row by row"""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(200, 2500))
+    dim = int(rng.choice([4, 8, 16, 32]))
+    isd = int(rng.choice([1, 2, 3, 7, 16, 64, 100]))
+    pd = int(rng.integers(1, 5))
+    rows = oracle.synth_rows(seed * 10007, n, dim)
+    bp = oracle.default_build_params(seed=seed + 1)
+    oix = oracle.Index.generate(rows, np.arange(n), bp, dim=dim, sum_mode=oracle.SUM_BLOCKED64)
+    store = ph.VectorStore(rows[:, :dim])
+    g = ph.Hnsw.from_layers(store, [oix.layer(l) for l in range(oix.layer_count)])
+    d0 = (1.0 - rows[:, :dim] @ rows[int(rng.integers(0, n)), :dim]) / 2
+    thr = np.float32(np.quantile(d0, float(rng.choice([0.01, 0.05, 0.2, 0.6, 1.0]))))
+    ti, td, tl = oix.threshold_nn(thr, pd, isd, max_out=n)
+    _same_threshold_rows(g.threshold_nn(float(thr), pd, isd, max_out=n), ti, td, tl)
+    monkeypatch.setenv("PHNSW_THRESHOLD_ALL_BIG", "1")
+    monkeypatch.setenv("PHNSW_THRESHOLD_BIG_PIECE", str(int(rng.integers(50, 3000))))
+    _same_threshold_rows(g.threshold_nn(float(thr), pd, isd, max_out=n), ti, td, tl)
+
+
 def test_serialize_layout_and_roundtrip(tmp_path):
     """serialize_hnsw / deserialize_hnsw  serialize.rs:33-209"""
     n, dim = 1500, 16
