@@ -1163,8 +1163,7 @@ extern "C" int phnsw_threshold_nn(const phnsw_index *ix, float threshold, uint64
   const phnsw_store *s = ix->store;
   PH_HIP(hipSetDevice(s->device));
   const PhLayerHost &L = ix->layers.back();
-  // the LDS queues hold 1024 entries (512 over a shared-codebook store: its kernels come with queues of 128 and 512)
-  const uint32_t n = L.n_nodes, CAPMAX = s->codes16 ? 512 : 1024, CHUNK = 16384;
+  const uint32_t n = L.n_nodes, CAPMAX = 1024, CHUNK = 16384;  // the LDS queues hold 1024 entries
   phnsw_search_params sp = {initial_search_depth, initial_search_depth, probe_depth};
   std::vector<uint32_t> h_nodes(n);
   PH_HIP(hipMemcpy(h_nodes.data(), L.nodes, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -886,7 +886,7 @@ static ph_search_fn pick_kernel_pqr(int capc, int m) {
 static ph_search_fn pick_kernel_pqs(int capc, int nv) {
 #define PH_KS(C, N) \
   if (capc == C && nv == N) return (ph_search_fn)ph_search_kernel<C, DistPQS<N>>;
-  PH_KS(2, 1) PH_KS(2, 3) PH_KS(2, 6) PH_KS(8, 1) PH_KS(8, 3) PH_KS(8, 6)
+  PH_KS(2, 1) PH_KS(2, 3) PH_KS(2, 6) PH_KS(8, 1) PH_KS(8, 3) PH_KS(8, 6) PH_KS(16, 1) PH_KS(16, 3) PH_KS(16, 6)
 #undef PH_KS
   return nullptr;
 }

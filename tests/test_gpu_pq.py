@@ -296,7 +296,7 @@ def test_reference_shaped_quantizer():
     # the same graph searched over the codes and over the reconstructions: identical bits
     g2 = ph.Hnsw.from_layers(rec, [(l.nodes, l.neighbors) for l in qh.hnsw.layers])
     q = oracle.synth_rows(2 ** 32, 150, dim)[:, :dim]
-    for sp in (ph.SearchParameters(64, 64, 2), ph.SearchParameters(300, 100, 3)):
+    for sp in (ph.SearchParameters(64, 64, 2), ph.SearchParameters(300, 100, 3), ph.SearchParameters(1000, 300, 2)):
         a = qh.hnsw.search_batch(queries=q, sp=sp, stats=True)
         b = g2.search_batch(queries=q, sp=sp, stats=True)
         for x, y in zip(a, b):
