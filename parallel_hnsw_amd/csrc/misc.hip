@@ -212,6 +212,8 @@ hipError_t ph_timed_malloc(void **p, size_t bytes) {
   g_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   g_alloc_calls++;
   if (e == hipSuccess) g_alloc_bytes += bytes;
+  static const bool log_it = getenv("PHNSW_ALLOC_LOG") != nullptr;
+  if (log_it && bytes >= (64u << 20)) fprintf(stderr, "[phnsw] hipMalloc %.2f GB\n", bytes / 1e9);
   return e;
 }
 hipError_t ph_timed_free(void *p) {

@@ -145,7 +145,8 @@ struct PhWorkspace {
 // list changes (epoch).  17 % of a 1M build's GPU time was recomputing it every round.
 struct PhBuildTable {
   float *D = nullptr;       // rows [lo_alloc, hi_alloc) x stride
-  size_t bytes = 0;
+  size_t bytes = 0;         // ... in use; `cap` allocated
+  size_t cap = 0;
   const uint32_t *qnodes = nullptr, *tnodes = nullptr;  // identity of layer X and of the table layer
   uint32_t qn = 0, tn = 0, T = 0, stride = 0;
   uint32_t lo_alloc = 0, hi_alloc = 0, lo = 0, hi = 0;  // allocated rows; valid rows [lo, hi)
@@ -166,6 +167,9 @@ struct phnsw_index {
   std::vector<PhHostStage *> stages;  // handed out under stage_mutex, one per concurrent host-pointer call
   std::mutex stage_mutex;
   std::vector<PhBuildTable> bt;  // one per layer whose nodes query; build entry points only (exclusive access to the index)
+  // buffers of dropped tables, reused by the next table that fits: a build re-makes its tables whenever a promotion
+  // changes a node list, and device allocation is host work whose cost varies with what else the host is doing
+  std::vector<std::pair<float *, size_t>> bt_spare;
   bool bt_enabled = false;    // set for the duration of a build / improve_index call: nothing else may keep 29 GB
   uint64_t nodes_epoch = 0;   // bumped whenever a layer's node list is created, replaced or dropped
   PhPendingLayer *pending = nullptr;  // layer under construction (phase API, build.hip)

@@ -615,12 +615,52 @@ void ph_build_table_free(phnsw_index *ix) {
   for (PhBuildTable &b : ix->bt)
     if (b.D) ph_timed_free(b.D);
   ix->bt.clear();
+  for (auto &sp : ix->bt_spare) ph_timed_free(sp.first);
+  ix->bt_spare.clear();
 }
-static void build_table_drop(PhBuildTable &b) {  // the rows go, the slot (which layer it belongs to) stays
-  if (b.D) ph_timed_free(b.D);
+// the rows go, the slot (which layer it belongs to) stays; the buffer waits for the next table that fits
+static void build_table_drop(phnsw_index *ix, PhBuildTable &b) {
+  if (b.D) ix->bt_spare.emplace_back(b.D, b.cap);
   b.D = nullptr;
-  b.bytes = 0;
+  b.bytes = b.cap = 0;
   b.lo = b.hi = b.lo_alloc = b.hi_alloc = 0;
+}
+// every table is void (a node list changed): the slots go, the buffers are kept for their successors
+static void build_table_recycle(phnsw_index *ix) {
+  for (PhBuildTable &b : ix->bt) build_table_drop(ix, b);
+  ix->bt.clear();
+}
+// a buffer of at least `bytes`: the smallest spare that holds them without wasting more than half of itself, or a new
+// allocation with a sixteenth of headroom (a promotion grows a layer by a few per cent)
+static float *build_table_buffer(phnsw_index *ix, size_t bytes, size_t *cap) {
+  int best = -1;
+  for (size_t i = 0; i < ix->bt_spare.size(); i++)
+    if (ix->bt_spare[i].second >= bytes && ix->bt_spare[i].second <= 2 * bytes &&
+        (best < 0 || ix->bt_spare[i].second < ix->bt_spare[(size_t)best].second))
+      best = (int)i;
+  if (best >= 0) {
+    float *p = ix->bt_spare[(size_t)best].first;
+    *cap = ix->bt_spare[(size_t)best].second;
+    ix->bt_spare.erase(ix->bt_spare.begin() + best);
+    return p;
+  }
+  size_t mfree = 0, mtotal = 0;
+  if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) return nullptr;
+  size_t want = bytes + bytes / 16;
+  if (want + (8ull << 30) > mfree) {  // the searches' own workspaces come first: give the spares back, then try the bare size
+    for (auto &sp : ix->bt_spare) ph_timed_free(sp.first);
+    ix->bt_spare.clear();
+    if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) return nullptr;
+    want = bytes;
+  }
+  if (want + (8ull << 30) > mfree || bytes > mtotal / 2) return nullptr;
+  float *p = nullptr;
+  if (ph_timed_malloc((void **)&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *cap = want;
+  return p;
 }
 
 // rows kept only for table layers of at least this many nodes (smaller tables cost less than the bookkeeping);
@@ -641,7 +681,7 @@ int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, co
   if (tn < build_table_min() || h.qn == 0) return 0;
   // one table per querying layer (an outer round of improve_neighbors_upto links every layer in turn); a changed node
   // list anywhere (epoch) voids them all
-  if (!ix->bt.empty() && ix->bt[0].epoch != ix->nodes_epoch) ph_build_table_free(ix);
+  if (!ix->bt.empty() && ix->bt[0].epoch != ix->nodes_epoch) build_table_recycle(ix);
   PhBuildTable *found = nullptr;
   for (PhBuildTable &b : ix->bt)
     if (b.qnodes == h.qnodes && b.qn == h.qn) found = &b;
@@ -657,21 +697,15 @@ int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, co
   const uint32_t need_lo = h.contiguous ? h.first : 0u, need_hi = h.contiguous ? h.first + h.count : h.qn;
   if (need_hi > h.qn || need_lo >= need_hi) return 0;
   const bool same = B.D && B.tnodes == tnodes && B.tn == tn && B.T == T;
-  if (B.D && !same) build_table_drop(B);
+  if (B.D && !same) build_table_drop(ix, B);
   if (!h.contiguous && !(B.D && B.lo <= need_lo && B.hi >= need_hi)) return 0;  // a sample: only from rows already there
   if (!B.D || need_lo < B.lo_alloc || need_hi > B.hi_alloc) {
     // (re)allocate for the requested range: the whole layer on one GPU, a rank's node range in a sharded build
     if (B.D && (need_lo > B.lo_alloc || need_hi < B.hi_alloc)) return 0;  // a second, different range: not worth juggling
-    build_table_drop(B);
+    build_table_drop(ix, B);
     const size_t bytes = (size_t)(need_hi - need_lo) * stride * 4u;
-    size_t mfree = 0, mtotal = 0;
-    PH_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if (bytes + (8ull << 30) > mfree || bytes > mtotal / 2) return 0;  // the searches' own workspaces come first
-    if (ph_timed_malloc((void **)&B.D, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      B.D = nullptr;
-      return 0;
-    }
+    B.D = build_table_buffer(ix, bytes, &B.cap);
+    if (!B.D) return 0;
     B.bytes = bytes;
     B.qnodes = h.qnodes;
     B.qn = h.qn;
