@@ -890,6 +890,8 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
         # batch on both lanes, each lane with its own outputs)
         two = None
         try:
+            if os.environ.get("BENCH_NO_PQ_TWO"):
+                raise RuntimeError("skipped (BENCH_NO_PQ_TWO)")
             spq = ph.SearchParameters(best["ef"], best["ef"], best["probe_depth"])
             lanes = [(pids, pd_, pln, pstatus, pst, stream)]
             s2 = torch.cuda.Stream(device=dev)
@@ -909,7 +911,8 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
                 go(i)
             torch.cuda.synchronize()
             dt2 = (time.perf_counter() - t0) / k_steps
-            same = bool((lanes[0][0][:, :best["ef"]] == lanes[1][0][:, :best["ef"]]).all())
+            cnt_ = nq * best["ef"]  # rows are written with a stride of number_of_candidates
+            same = bool((lanes[0][0].view(-1)[:cnt_] == lanes[1][0].view(-1)[:cnt_]).all())
             two = {"ms_per_step": round(dt2 * 1e3, 3), "queries_per_s": round(nq / dt2), "both_lanes_identical": same}
             log("  pq ef=%d pd=%d, two batches in flight: %.3f ms per step = %.0f q/s" % (best["ef"], best["probe_depth"], dt2 * 1e3, nq / dt2))
             del lanes
