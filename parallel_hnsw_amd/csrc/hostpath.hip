@@ -85,40 +85,12 @@ int grow(T **p, size_t *have, size_t need, const char *what) {
   return 0;
 }
 
-// HIP maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams that
-// share one run their work in issue order: a chunk pipeline over such a pair does not overlap at all (measured: the
-// 10 000-query call 15.2 instead of 12.4 ms when the process had made exactly two streams before -- or six with eight
-// queues).  So the pair is tried once: a kernel that spins for a millisecond on one stream, an empty one on the other;
-// if the empty one has to wait, the second stream is replaced (the next one lands on another queue) and tried again.
-__global__ void ph_spin_kernel(uint64_t ticks) {
-  const uint64_t t0 = wall_clock64();  // 100 MHz
-  while (wall_clock64() - t0 < ticks) {
-  }
-}
-__global__ void ph_noop_kernel() {}
-
+// the pipeline needs its two streams on different hardware queues (ph_stream_beside, misc.hip): tried once per staging set
 int pair_streams(PhHostStage &st) {
-  if (st.streams_checked || getenv("PHNSW_HOST_NO_STREAM_CHECK")) return 0;
+  if (st.streams_checked) return 0;
   Slot &a = st.slot[0], &b = st.slot[1];
-  if (!a.stream || !b.stream) return 0;
-  for (int attempt = 0; attempt < 6; attempt++) {
-    PH_HIP(hipStreamSynchronize(a.stream));
-    PH_HIP(hipStreamSynchronize(b.stream));
-    hipLaunchKernelGGL(ph_noop_kernel, dim3(1), dim3(64), 0, b.stream);  // first-launch costs out of the way
-    PH_HIP(hipStreamSynchronize(b.stream));
-    hipLaunchKernelGGL(ph_spin_kernel, dim3(1), dim3(64), 0, a.stream, (uint64_t)100000);  // 1 ms
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(ph_noop_kernel, dim3(1), dim3(64), 0, b.stream);
-    PH_HIP(hipStreamSynchronize(b.stream));
-    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    PH_HIP(hipStreamSynchronize(a.stream));
-    PH_HIP(hipGetLastError());
-    if (waited < 0.5e-3) break;  // side by side
-    hipStream_t fresh = nullptr;
-    PH_HIP(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
-    hipStreamDestroy(b.stream);
-    b.stream = fresh;
-  }
+  if (!a.stream) return 0;
+  PH_TRY(ph_stream_beside(a.stream, &b.stream));
   st.streams_checked = true;
   return 0;
 }

@@ -272,6 +272,7 @@ hipError_t ph_timed_free(void *p);
 #define hipMalloc(p, n) ph_timed_malloc((void **)(p), (n))
 #define hipFree(p) ph_timed_free((void *)(p))
 #endif
+int ph_stream_beside(hipStream_t other, hipStream_t *io);  // a non-blocking stream on another hardware queue than `other` (misc.hip)
 hipError_t ph_pool_alloc(void **p, size_t bytes);
 void ph_pool_free(void *p);
 void ph_pool_trim(void);  // give everything cached back to the driver

@@ -160,7 +160,7 @@ struct Driver {
     } else if (comm.host_buffers) {
       rc = comm.all_gather(comm.ctx, send, recv, bytes, nullptr);
     } else {
-      if (!stream) PH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      if (!stream) PH_TRY(ph_stream_beside(nullptr, &stream));  // beside the engine's launches (the null stream), not behind them
       // the phase that filled `send` has synchronised the device (every phase of the engine ends with the
       // host reading its status words), so the transfer may start at once on the collectives' stream
       rc = comm.all_gather(comm.ctx, send, recv, bytes, stream);
