@@ -385,25 +385,27 @@ def worker(args):
         run2 = Runner(index, qstore2, ef_max=ef)
         gt2 = ground_truth(store, qstore2)
         # HIP maps streams onto a few hardware queues, and two streams that share one do not overlap (host
-        # path): the second lane's stream is tested against the first and replaced until they run side by side
+        # path): the second lane's stream comes from the library, which tests it against the first
+        # (phnsw_stream_create_beside: a kernel that spins on one stream, an empty one on the candidate)
+        stream2 = ph.stream_create_beside(local, stream)
+
         def side_by_side(s_b):
+            """the same test from here, for the line: does a launch on s_b wait for work on lane 0's stream?"""
+            ext = torch.cuda.ExternalStream(s_b, device=dev)
+            with torch.cuda.stream(ext):
+                torch.zeros(16, device=dev)           # first-use costs out of the way
             torch.cuda.synchronize()
             torch.cuda._sleep(4_000_000)              # about 2 ms of spinning on the current stream (lane 0)
             t0 = time.perf_counter()
-            with torch.cuda.stream(s_b):
+            with torch.cuda.stream(ext):
                 torch.zeros(16, device=dev)
-            s_b.synchronize()
+            ext.synchronize()
             waited = time.perf_counter() - t0
             torch.cuda.synchronize()
             return waited < 0.8e-3
-        stream2, lane_tries = torch.cuda.Stream(device=dev), 1
-        with torch.cuda.stream(stream2):
-            torch.zeros(16, device=dev)               # first-use costs out of the way
-        while not side_by_side(stream2) and lane_tries < 8:
-            stream2, lane_tries = torch.cuda.Stream(device=dev), lane_tries + 1
         lanes_ok = side_by_side(stream2)
-        log("second lane: stream %d of this process, runs beside the first: %s" % (lane_tries, lanes_ok))
-        lanes = [(run, stream), (run2, stream2.cuda_stream)]
+        log("second lane: phnsw_stream_create_beside; runs beside the first: %s" % lanes_ok)
+        lanes = [(run, stream), (run2, stream2)]
         torch.cuda.synchronize()
 
         def timed(lane_of_step):
@@ -913,9 +915,9 @@ def pq_cells(args, log, ph, torch, store, index, qstore, gt, recall_at_10, dev, 
                 raise RuntimeError("skipped (BENCH_NO_PQ_TWO)")
             spq = ph.SearchParameters(best["ef"], best["ef"], best["probe_depth"])
             lanes = [(pids, pd_, pln, pstatus, pst, stream)]
-            s2 = torch.cuda.Stream(device=dev)
+            s2 = ph.stream_create_beside(dev.index or 0, stream)
             lanes.append((torch.empty_like(pids), torch.empty_like(pd_), torch.empty_like(pln), torch.empty_like(pstatus),
-                          torch.empty_like(pst), s2.cuda_stream))
+                          torch.empty_like(pst), s2))
             k_steps = 10
 
             def go(i):

@@ -207,6 +207,13 @@ int phnsw_search_batch_device(const phnsw_index *ix, const float *queries_dev, u
                               uint32_t upto_layers, const uint32_t *exclude_dev,
                               uint32_t *out_ids_dev, float *out_d_dev, uint32_t *out_len_dev,
                               uint32_t *out_stats_dev, uint32_t *status_dev, void *stream);
+/* Throughput callers keep TWO batches in flight: phnsw_search_batch_device calls issued alternately on two streams
+ * overlap (an index holds two search workspaces) -- if the two streams sit on different hardware queues.  HIP maps a
+ * process's streams onto a few of them (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one run in issue
+ * order.  This makes a non-blocking stream that was SEEN to run beside `other_stream` (a hipStream_t; NULL = the
+ * default stream): a kernel spinning for a millisecond on `other_stream`, an empty one on the candidate, up to six
+ * candidates.  *out_stream is a hipStream_t the caller destroys with hipStreamDestroy. */
+int phnsw_stream_create_beside(int device, void *other_stream, void **out_stream);
 /* timing of the last phnsw_search_batch_device launch on this index measured with HIP
  * events on its stream: kernel milliseconds */
 /* running totals of distance evaluations and hops over every search launched on the index since

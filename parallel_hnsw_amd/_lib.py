@@ -124,6 +124,7 @@ SYMBOLS = {
     "phnsw_search_batch": (_i32, [_vp, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp, _vp, _vp]),
     "phnsw_search_batch_stored": (_i32, [_vp, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp, _vp, _vp]),
     "phnsw_search_batch_topk": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _u64, _vp, _vp, _vp]),
+    "phnsw_stream_create_beside": (_i32, [_i32, _vp, C.POINTER(_vp)]),
     "phnsw_search_instrumented": (_i32, [_vp, _vp, _vp, _u64, C.POINTER(SearchParams), _vp, _vp, _vp, _vp]),
     "phnsw_search_batch_device": (_i32, [_vp, _vp, _u32, _vp, _u64, C.POINTER(SearchParams), _u32, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp]),

@@ -635,6 +635,19 @@ extern "C" uint64_t phnsw_debug_two_launch_count(void) { return g_two_launch_cou
 // chunks of the last descent on this index (phnsw_last_search_dispatches then describes the last one)
 extern "C" uint32_t phnsw_debug_last_search_chunks(const phnsw_index *ix) { return ix ? ix->ws[ix->ws_last].n_chunks : 0; }
 
+extern "C" int phnsw_stream_create_beside(int device, void *other_stream, void **out_stream) try {
+  if (!out_stream) {
+    ph_set_error("phnsw_stream_create_beside: out_stream is NULL");
+    return PHNSW_E_INVALID;
+  }
+  PH_HIP(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  int rc = ph_stream_beside((hipStream_t)other_stream, &st);
+  if (rc) return rc;
+  *out_stream = (void *)st;
+  return 0;
+} catch (...) { return ph_caught(); }
+
 // enqueue one search launch; caller owns all device buffers
 int ph_search_device(const phnsw_index *ix, const float *queries_dev, uint32_t ldq, const uint32_t *qids_dev,
                      uint64_t nq, const phnsw_search_params *sp, uint32_t upto, const uint32_t *exclude_dev,

@@ -23,6 +23,16 @@ EMPTY = 0xFFFFFFFFFFFFFFFF  # VectorId::MAX / NodeId::MAX (types.rs:8-13)
 METRIC_COSINE_HALF, METRIC_ONE_MINUS_DOT, METRIC_L2 = 0, 1, 2
 
 
+def stream_create_beside(device=0, other_stream=0):
+    """phnsw_stream_create_beside: a non-blocking hipStream_t (as an integer) that was seen to run beside `other_stream`
+    (0 = the default stream) -- the second lane of a caller that keeps two batches in flight.  Streams that share a
+    hardware queue do not overlap; hipStreamDestroy is the caller's."""
+    import ctypes
+    out = ctypes.c_void_p()
+    check(lib().phnsw_stream_create_beside(int(device), ctypes.c_void_p(int(other_stream) or None), ctypes.byref(out)))
+    return int(out.value or 0)
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

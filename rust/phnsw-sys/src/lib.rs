@@ -212,6 +212,8 @@ extern "C" {
     pub fn phnsw_search_instrumented(ix: *const phnsw_index, queries: *const c_float, qids: *const u64, nq: u64,
                                      sp: *const phnsw_search_params, out_ids: *mut u64, out_d: *mut c_float,
                                      out_len: *mut u64, out_index_distance: *mut u64) -> c_int;
+    /// a non-blocking hipStream_t seen to run beside `other_stream` (NULL = the default stream): lanes for two batches in flight
+    pub fn phnsw_stream_create_beside(device: c_int, other_stream: *mut c_void, out_stream: *mut *mut c_void) -> c_int;
     pub fn phnsw_search_batch_device(ix: *const phnsw_index, queries_dev: *const c_float, ldq: u32,
                                      qids_dev: *const u32, nq: u64, sp: *const phnsw_search_params,
                                      upto_layers: u32, exclude_dev: *const u32, out_ids_dev: *mut u32,

@@ -265,6 +265,38 @@ def test_index_counters_sum_the_per_query_stats():
     assert g.counters() == (int(st[:, 0].sum() + st2[:, 0].sum()), int(st[:, 1].sum() + st2[:, 1].sum()))
 
 
+def test_two_batches_in_flight_on_two_streams():
+    """a throughput caller's arrangement: two query batches alternate over two streams (the second one made by
+    phnsw_stream_create_beside, which tests that it runs beside the first); every launch gives the rows the oracle
+    gives, whichever lane it ran on and whatever ran beside it"""
+    import torch
+    rows, ix = build_oracle_index(6000, 64, seed=9)
+    store, g = to_gpu(rows, 64, ix, oracle.METRIC_COSINE_HALF)
+    dev = torch.device("cuda", 0)
+    sp, spt = ph.SearchParameters(64, 64, 3), (64, 64, 3)
+    s1 = ph.stream_create_beside(0, 0)
+    assert s1 != 0
+    lanes = []
+    for k, st in enumerate((0, s1)):
+        q = np.ascontiguousarray(oracle.synth_rows(2 ** 32 + 7919 * k, 3000, 64)[:, :64])
+        qd = torch.from_numpy(q).to(dev)
+        lanes.append(dict(q=q, qd=qd, ld=64, stream=st,
+                          ids=torch.empty((3000, 64), dtype=torch.int32, device=dev), d=torch.empty((3000, 64), dtype=torch.float32, device=dev),
+                          ln=torch.empty(3000, dtype=torch.int32, device=dev), status=torch.empty(3000, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for i in range(8):
+        a = lanes[i & 1]
+        g.search_batch_device(3000, sp, a["ids"].data_ptr(), a["d"].data_ptr(), a["ln"].data_ptr(), a["status"].data_ptr(),
+                              queries=a["qd"].data_ptr(), ldq=a["ld"], stream=a["stream"])
+    torch.cuda.synchronize()
+    for a in lanes:
+        ci, cd, cl = ix.search(queries=a["q"], sp=spt)
+        assert int(a["status"].abs().sum()) == 0 and int(cl.min()) == 64
+        np.testing.assert_array_equal(a["ln"].cpu().numpy().astype(np.uint64), cl.astype(np.uint64))
+        np.testing.assert_array_equal(a["ids"].cpu().numpy().view(np.uint32).astype(np.uint64), ci.astype(np.uint64))
+        np.testing.assert_array_equal(a["d"].cpu().numpy().view(np.uint32), cd.view(np.uint32))
+
+
 def test_concurrent_host_threads_share_an_index():
     """search(&self) is re-entrant in the reference (Rayon calls it from many threads, lib.rs:1107-1117);
     here concurrent callers share the index's two workspaces behind a mutex"""
