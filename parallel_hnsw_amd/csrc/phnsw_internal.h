@@ -218,6 +218,9 @@ struct PhSearchArgs {
   // queue of cap_max (id, distance) slots in global memory
   const uint32_t *knn_nodes;
   uint32_t *big_q;
+  // dense layers: a query's table row is staged in LDS when the table layer has at most this many nodes
+  // (PH_TINY_LDS_NODES; the one-wave-per-SIMD kernels of small batches raise it to what a CU's LDS holds)
+  uint32_t tiny_lds_nodes;
   float hit_eps;        // out_hit: > 0 selects match_within_epsilon (search.rs:173-187)
   uint32_t out_stride;  // entries written per query (0 = ef); link rounds keep only the top M
   unsigned long long *totals;   // nullable: [2] running sums of distance evaluations / hops (all launches)

@@ -88,7 +88,7 @@ __device__ __forceinline__ void ph_search_body(const PhSearchArgs &a) {
   // dense top layers (tiny.hip): this query's row of the distance table and the visited bits of the
   // table ids, both in LDS; T = 0 when the launch has none (or its layers turned out not to be nested)
   const uint32_t T = (a.tiny_layers && a.tiny_member[a.tiny_n] == 0u) ? a.tiny_layers : 0u;
-  const bool tiny_lds_row = a.tiny_n <= PH_TINY_LDS_NODES;
+  const bool tiny_lds_row = a.tiny_n <= a.tiny_lds_nodes;
   float *Dl = (float *)(smem + 5 * CAP + 64);
   uint32_t *Vl = smem + 5 * CAP + 64 + (tiny_lds_row ? a.tiny_stride : 0u);
   const uint32_t tiny_words = (a.tiny_n + 31u) / 32u;
@@ -1134,7 +1134,6 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   const bool pq = ix->store->codes != nullptr;
   int capc = pick_capc(std::max(a.ef, a.cap_max)), nv = pq ? 0 : pick_nv(a.dist.nv4);
   const int pqr = ix->store->codes16 ? -1 : pick_pqr(ix->store, capc);
-  const size_t pq_lds = pq ? ((pqr || ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
   a.pq_tables = ws.pq_tables;
   a.pq_table_bytes = (uint32_t)ph_pq_lds_bytes(ix->store);
   ph_search_fn fn = nullptr;
@@ -1144,7 +1143,14 @@ int ph_search_launch(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, hi
   if (!pq && !pqr && a.nq <= PH_LATENCY_MAX && !getenv("PHNSW_NO_LAT") && pick_kernel_lat(capc, nv)) {
     fn = pick_kernel_lat(capc, nv);
     lat = -2;
+    // one wave per SIMD leaves each wave a quarter of the CU's LDS: room for the table row of a far larger table layer
+    // (7 331 nodes = 29 KB at 1M vectors), whose look-ups are then LDS reads instead of a global round trip per hop --
+    // as long as three blocks still fit a CU (a batch of up to 768 queries loses no slot)
+    if (a.tiny_layers && a.tiny_n > a.tiny_lds_nodes && !getenv("PHNSW_NO_LAT_LDS_ROW") &&
+        lds_bytes(capc, (size_t)a.tiny_stride * 4u + (size_t)((a.tiny_n + 31u) / 32u + 1u) * 4u) <= (160u * 1024u) / 3u)
+      a.tiny_lds_nodes = a.tiny_n;
   }
+  const size_t pq_lds = pq ? ((pqr || ph_pq_global_tables()) ? 0 : ph_pq_lds_bytes(ix->store)) : ph_tiny_lds_bytes(a);
   if (a.out_index) {  // Hnsw::search_instrumented
     if (pq || pqr) {
       ph_set_error("search_instrumented: f32 stores only");

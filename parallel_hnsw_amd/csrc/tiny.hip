@@ -444,7 +444,7 @@ uint64_t ph_tiny_max_positions(const phnsw_index *ix, uint32_t n_layers, uint32_
 
 size_t ph_tiny_lds_bytes(const PhSearchArgs &a) {
   if (!a.tiny_layers) return 0;
-  return (a.tiny_n <= PH_TINY_LDS_NODES ? (size_t)a.tiny_stride * 4u : 0u) + (size_t)((a.tiny_n + 31u) / 32u + 1u) * 4u;
+  return (a.tiny_n <= a.tiny_lds_nodes ? (size_t)a.tiny_stride * 4u : 0u) + (size_t)((a.tiny_n + 31u) / 32u + 1u) * 4u;
 }
 
 template <class T>
@@ -602,6 +602,7 @@ int ph_tiny_prepare(const phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, uin
   if (rc) return rc < 0 ? rc : 0;
   a.tiny_layers = T;
   a.tiny_n = tn;
+  a.tiny_lds_nodes = PH_TINY_LDS_NODES;
   a.tiny_stride = stride;
   a.tiny_d = ws.tiny_d;
   a.tiny_nbr = ws.tiny_nbr;
@@ -748,6 +749,7 @@ int ph_build_table_prepare(phnsw_index *ix, PhWorkspace &ws, PhSearchArgs &a, co
   if (rc) return rc < 0 ? rc : 0;
   a.tiny_layers = T;
   a.tiny_n = tn;
+  a.tiny_lds_nodes = PH_TINY_LDS_NODES;
   a.tiny_stride = stride;
   a.tiny_d = B.D;
   a.tiny_rows = 1;
