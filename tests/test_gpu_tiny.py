@@ -36,7 +36,7 @@ CASES = [
     (3000, 1536, ph.METRIC_COSINE_HALF, (128, 128, 2)),  # 6 chunks per lane: 4 queries per wave
     (5000, 200, ph.METRIC_L2, (300, 300, 2)),            # L2 chain, queue of 300
     (700, 64, ph.METRIC_COSINE_HALF, (32, 32, 3)),       # every layer is a dense one
-    (30000, 128, ph.METRIC_COSINE_HALF, (64, 64, 2)),    # table layer of ~2500 nodes: its rows stay in global memory
+    (30000, 128, ph.METRIC_COSINE_HALF, (64, 64, 2)),    # table layer of ~2500 nodes: past PH_TINY_LDS_NODES (rows in global memory; in LDS on the small-batch kernels)
     (8000, 256, ph.METRIC_ONE_MINUS_DOT, (64, 64, 2)),   # one whole chunk per lane: the matrix-core table, 4 steps per leaf
 ]
 
